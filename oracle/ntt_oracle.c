@@ -1,0 +1,358 @@
+/*
+ * ntt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See ntt_oracle.h.
+ *
+ * Restates, stage by stage and in the reference's own evaluation order, what the CUDA kernels
+ * of ozgunozerk/NTT-Cuda compute.  Citations are relative to /root/reference/BFV_Scheme/.
+ * The reference's uint128_t (uint128.h:10-129) is replaced by the compiler's unsigned __int128;
+ * SURVEY.md 8(a) lists the host-side quirks of uint128_t that are deliberately NOT reproduced
+ * (they never fire for values the reference feeds them).
+ */
+#include "ntt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ helpers */
+
+/* demo.cu:69 / decryption_test.cu:60 : q_bit_lengths.push_back(log2((double)q) + 1) */
+unsigned orc_bit_length(u64 q) { return (unsigned)(log2((double)q) + 1); }
+
+/* 60bit_ntt_test.cu:47-49 : mu = (uint128_t::exp2(2*bit_length) / q).low */
+u64 orc_mu(u64 q, unsigned k) { return (u64)((((u128)1) << (2 * k)) / q); }
+
+/* host64x2(a,b) % m  (uint128.h:314-341 schoolbook multiply, :278-312 shift-subtract remainder) */
+u64 orc_mulmod(u64 a, u64 b, u64 m) { return (u64)(((u128)a * b) % m); }
+
+/* helper.h:8-28 modpow128: note res starts as a (unreduced) when b is odd */
+u64 orc_modpow(u64 a, u64 b, u64 m)
+{
+    u64 res = 1;
+    if (1 & b) res = a;
+    while (b != 0) {
+        b = b >> 1;
+        a = orc_mulmod(a, a, m);
+        if (b & 1) res = orc_mulmod(res, a, m);
+    }
+    return res;
+}
+
+/* helper.h:52-56 modinv128: Fermat, a^(q-2) */
+u64 orc_modinv(u64 a, u64 q) { return orc_modpow(a, q - 2, q); }
+
+/* helper.h:58-70 */
+u64 orc_bitrev(u64 a, int bits)
+{
+    u64 res = 0;
+    for (int i = 0; i < bits; i++) {
+        res <<= 1;
+        res = (a & 1) | res;
+        a >>= 1;
+    }
+    return res;
+}
+
+/* parameter.h:5-20 fillTablePsi128: tab[i] = psi^bitReverse(i, log2(n)) mod q */
+void orc_fill_table(u64 psi, u64 q, u64* tab, unsigned n)
+{
+    int lg = (int)log2((double)n);
+    for (unsigned i = 0; i < n; i++) tab[i] = orc_modpow(psi, orc_bitrev(i, lg), q);
+}
+
+/* parameter.h:31-79 getParams (the active, un-commented sets) + the commented 58-bit n=4096 set
+ * (:43-47) under the pseudo-size n = 4096 + 1 so tests can reach it. */
+int orc_get_params(u64 n, u64* q, u64* psi, u64* psiinv, u64* ninv, unsigned* qbit)
+{
+    switch (n) {
+    case 2048:  *q = 137438691329ULL;      *psi = 22157790ULL;       *psiinv = 88431458764ULL;        *ninv = 137371582593ULL;       *qbit = 37; return 0;
+    case 4096:  *q = 33538049ULL;          *psi = 2386ULL;           *psiinv = 26102329ULL;           *ninv = 33529861ULL;           *qbit = 25; return 0;
+    case 4097:  *q = 288230376135196673ULL; *psi = 60193018759093ULL; *psiinv = 236271020333049746ULL; *ninv = 288160007391023041ULL; *qbit = 58; return 0;
+    case 8192:  *q = 8796092858369ULL;     *psi = 1734247217ULL;     *psiinv = 5727406356888ULL;      *ninv = 8795019116565ULL;      *qbit = 43; return 0;
+    case 16384: *q = 281474976546817ULL;   *psi = 23720796222ULL;    *psiinv = 129310633907832ULL;    *ninv = 281457796677643ULL;    *qbit = 48; return 0;
+    case 32768: *q = 36028797017456641ULL; *psi = 1155186985540ULL;  *psiinv = 31335194304461613ULL;  *ninv = 36027697505828911ULL;  *qbit = 55; return 0;
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------ Barrett */
+
+/* mul64 (uint128.h:353-373) followed by singleBarrett (ntt_60bit.cuh:44-61); the pointwise kernels
+ * inline the same sequence (poly_arithmetic.cuh:18-33).  Every intermediate the reference keeps only
+ * the .low limb of is truncated to 64 bits here as well. */
+static inline u64 barrett128(u128 a, u64 q, u64 mu, unsigned k)
+{
+    u128 rx;
+    rx = (u64)(a >> (k - 2));            /* rx = a >> (qbit - 2); only rx.low is used next           */
+    rx = (u128)(u64)rx * mu;             /* mul64(rx.low, mu, rx)                                     */
+    rx = rx >> (k + 2);                  /* uint128_t::shiftr(rx, qbit + 2)                           */
+    rx = (u128)(u64)rx * q;              /* mul64(rx.low, q, rx)                                      */
+    a = a - rx;                          /* sub128(a, rx)                                             */
+    u64 lo = (u64)a;                     /* only a.low is inspected                                   */
+    if (lo >= q) lo -= q;                /* ONE conditional subtraction                               */
+    return lo;
+}
+
+u64 orc_barrett(u64 a, u64 b, u64 q, u64 mu, unsigned k) { return barrett128((u128)a * b, q, mu, k); }
+
+/* ------------------------------------------------------------------- stages */
+
+/* One Cooley-Tukey stage, CTBasedNTTInner<l,n> (ntt_60bit.cuh:192-223); the shared-memory kernel
+ * CTBasedNTTInnerSingle (:63-123) runs the same butterflies with g = local + blockIdx.x*(n/2l). */
+void orc_ct_stage(u64* a, unsigned n, unsigned length, u64 q, u64 mu, unsigned k, const u64* psi_tab)
+{
+    unsigned step = (n / length) / 2;
+    for (unsigned g = 0; g < n / 2; g++) {
+        unsigned psi_step = g / step;
+        unsigned j = psi_step * step * 2 + g % step;
+        u64 psi = psi_tab[length + psi_step];
+        u64 U = a[j];
+        u64 V = barrett128((u128)a[j + step] * psi, q, mu, k);
+        u64 t = U + V;
+        t -= q * (t >= q);
+        a[j] = t;
+        U += q * (U < V);
+        a[j + step] = U - V;
+    }
+}
+
+/* One Gentleman-Sande stage with the n^-1 halving folded in, GSBasedINTTInner<l,n> (:225-265);
+ * GSBasedINTTInnerSingle (:125-190) is the same arithmetic in shared memory. */
+void orc_gs_stage(u64* a, unsigned n, unsigned length, u64 q, u64 mu, unsigned k, const u64* psiinv_tab)
+{
+    unsigned step = (n / length) / 2;
+    u64 q2 = (q + 1) >> 1;
+    for (unsigned g = 0; g < n / 2; g++) {
+        unsigned psi_step = g / step;
+        unsigned j = psi_step * step * 2 + g % step;
+        u64 psiinv = psiinv_tab[length + psi_step];
+        u64 U = a[j];
+        u64 V = a[j + step];
+        u64 t = U + V;
+        t -= q * (t >= q);
+        a[j] = (t >> 1) + q2 * (t & 1);
+        U += q * (U < V);
+        u64 d = barrett128((u128)(U - V) * psiinv, q, mu, k);
+        a[j + step] = (d >> 1) + q2 * (d & 1);
+    }
+}
+
+/* forwardNTT (:314-348): stages length = 1,2,...,n/2 in that order (global-memory stages first,
+ * then the single-block kernel loops length = l ... n/2, :78-80). */
+void orc_forward(u64* a, unsigned n, u64 q, u64 mu, unsigned k, const u64* psi_tab)
+{
+    for (unsigned length = 1; length < n; length *= 2) orc_ct_stage(a, n, length, q, mu, k, psi_tab);
+}
+
+/* inverseNTT (:350-386): stages length = n/2, n/4, ..., 1 (:144-146, then the global stages). */
+void orc_inverse(u64* a, unsigned n, u64 q, u64 mu, unsigned k, const u64* psiinv_tab)
+{
+    for (unsigned length = n / 2; length >= 1; length /= 2) orc_gs_stage(a, n, length, q, mu, k, psiinv_tab);
+}
+
+/* forwardNTT_batch / inverseNTT_batch (:608-697) with the *_batch kernels' index rules (:391-422):
+ * index = blockIdx.y % division selects q/mu/qbit and the twiddle table; data offset blockIdx.y*n. */
+void orc_forward_batch(u64* a, unsigned n, const u64* psi_tabs, unsigned num, unsigned division,
+                       const u64* q, const u64* mu, const unsigned* k, int threads)
+{
+    (void)threads;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (long y = 0; y < (long)num; y++) {
+        unsigned idx = (unsigned)y % division;
+        orc_forward(a + (size_t)y * n, n, q[idx], mu[idx], k[idx], psi_tabs + (size_t)idx * n);
+    }
+}
+
+void orc_inverse_batch(u64* a, unsigned n, const u64* psiinv_tabs, unsigned num, unsigned division,
+                       const u64* q, const u64* mu, const unsigned* k, int threads)
+{
+    (void)threads;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (long y = 0; y < (long)num; y++) {
+        unsigned idx = (unsigned)y % division;
+        orc_inverse(a + (size_t)y * n, n, q[idx], mu[idx], k[idx], psiinv_tabs + (size_t)idx * n);
+    }
+}
+
+/* ---------------------------------------------------------------- pointwise */
+
+/* barrett (poly_arithmetic.cuh:9-34): a[i] = a[i]*b[i] mod q; final select is `rc.low < q ? rc.low : rc.low-q` */
+void orc_pointwise(u64* a, const u64* b, unsigned n, u64 q, u64 mu, unsigned k)
+{
+    for (unsigned i = 0; i < n; i++) a[i] = barrett128((u128)a[i] * b[i], q, mu, k);
+}
+
+/* barrett_batch (:36-66) when c == a, barrett_batch_3param (:68-98) otherwise.  b is indexed with the
+ * same i = x + y*n as a (the reference passes b = public_key / secret_key laid out per polynomial). */
+void orc_pointwise_batch(u64* c, const u64* a, const u64* b, unsigned n, unsigned num, unsigned division,
+                         const u64* q, const u64* mu, const unsigned* k)
+{
+    for (unsigned y = 0; y < num; y++) {
+        unsigned idx = y % division;
+        for (unsigned x = 0; x < n; x++) {
+            size_t i = (size_t)y * n + x;
+            c[i] = barrett128((u128)a[i] * b[i], q[idx], mu[idx], k[idx]);
+        }
+    }
+}
+
+/* barrett_int (:100-126) */
+void orc_pointwise_scalar(u64* a, u64 b, unsigned n, u64 q, u64 mu, unsigned k)
+{
+    for (unsigned i = 0; i < n; i++) a[i] = barrett128((u128)a[i] * b, q, mu, k);
+}
+
+/* ----------------------------------------------------- reference CPU check */
+
+/* refPolyMul128 (helper.h:95-126): O(n^2) schoolbook product modulo (x^n + 1, m) */
+void orc_ref_polymul(const u64* a, const u64* b, u64* d, u64 m, unsigned n)
+{
+    u64* c = (u64*)calloc((size_t)2 * n, sizeof(u64));
+    for (unsigned i = 0; i < n; i++)
+        for (unsigned j = 0; j < n; j++) {
+            c[i + j] = orc_mulmod(a[i], b[j], m) + c[i + j] % m;
+            c[i + j] %= m;
+        }
+    for (unsigned i = 0; i < n; i++) {
+        u64 ci = c[i];
+        if (ci < c[i + n]) ci += m;
+        d[i] = (ci - c[i + n]) % m;
+    }
+    free(c);
+}
+
+/* ------------------------------------------------------ BFV decryption KAT */
+
+/* decryption_test.cu:60-345 bootstrap constants.  Output arrays sized r (= r_plus_1 - 1) unless noted:
+ * psiinv[r+1], inv_punctured_q[r], neg_inv_q_mod_t_gamma[2], prod_t_gamma_mod_q[r],
+ * inv_q_last_mod_q[r] (old/encryption.cu:98 / decryption_test.cu:66-72), qi_div_t[r+1]. */
+void orc_bfv_constants(const u64* qs, const u64* psis, unsigned r_plus_1, u64 t, u64 gamma,
+                       u64* psiinv, u64* inv_punctured_q, u64* neg_inv_q_mod_t_gamma,
+                       u64* prod_t_gamma_mod_q, u64* inv_q_last_mod_q, u64* qi_div_t)
+{
+    unsigned r = r_plus_1 - 1;
+    for (unsigned i = 0; i < r_plus_1; i++) psiinv[i] = orc_modinv(psis[i], qs[i]);      /* :93-94 */
+    u64 mult_t = 1, mult_g = 1;                                                          /* :103-111 */
+    for (unsigned i = 0; i < r; i++) {
+        mult_t = orc_mulmod(mult_t, qs[i], t);
+        mult_g = orc_mulmod(mult_g, qs[i], gamma);
+    }
+    neg_inv_q_mod_t_gamma[0] = t - orc_modinv(mult_t, t);
+    neg_inv_q_mod_t_gamma[1] = gamma - orc_modinv(mult_g, gamma);
+    u128 prod_t_gamma = (u128)t * gamma;                                                 /* :119-125 */
+    for (unsigned i = 0; i < r; i++) prod_t_gamma_mod_q[i] = (u64)(prod_t_gamma % qs[i]);
+    for (unsigned i = 0; i < r; i++) {                                                   /* :262-276 */
+        u64 temp = 1;
+        for (unsigned j = 0; j < r; j++) {
+            if (i == j) continue;
+            temp = orc_mulmod(temp, qs[j], qs[i]);
+        }
+        inv_punctured_q[i] = orc_modinv(temp, qs[i]);
+    }
+    for (unsigned i = 0; i < r; i++) inv_q_last_mod_q[i] = orc_modinv(qs[r] % qs[i], qs[i]);   /* :66-72 */
+    for (unsigned i = 0; i < r_plus_1; i++) qi_div_t[i] = qs[i] / t;                              /* :82-86 */
+}
+
+int orc_bfv_decrypt(u64* c, const u64* sk, const u64* qs, const u64* psis, unsigned r_plus_1,
+                    unsigned n, u64 t, u64 gamma, u64* out, u64* stage_out)
+{
+    unsigned r = r_plus_1 - 1;
+    if (r_plus_1 > 16 || r < 1) return -1;
+    unsigned kbits[16]; u64 mus[16];
+    u64 psiinv[16], inv_punct[16], neg_inv[2], ptg[16], iql[16], qdt[16];
+    for (unsigned i = 0; i < r_plus_1; i++) {                      /* :57-61, :160-168 */
+        kbits[i] = orc_bit_length(qs[i]);
+        mus[i] = orc_mu(qs[i], kbits[i]);
+    }
+    orc_bfv_constants(qs, psis, r_plus_1, t, gamma, psiinv, inv_punct, neg_inv, ptg, iql, qdt);
+    const unsigned gamma_bits = 61;                                /* output_base_bit_lengths = {10, 61}, :98 */
+    u64 mu_gamma = orc_mu(gamma, gamma_bits);                      /* :252-258 */
+    u64 gamma_div_2 = gamma >> 1;                                  /* :91 */
+
+    u64* psi_tabs = (u64*)malloc(sizeof(u64) * (size_t)n * r_plus_1);      /* :178-199 */
+    u64* psiinv_tabs = (u64*)malloc(sizeof(u64) * (size_t)n * r_plus_1);
+    for (unsigned i = 0; i < r_plus_1; i++) {
+        orc_fill_table(psis[i], qs[i], psi_tabs + (size_t)i * n, n);
+        orc_fill_table(psiinv[i], qs[i], psiinv_tabs + (size_t)i * n, n);
+    }
+    u64 bcm[32];                                                   /* base_change_matrix, :281-301 */
+    u64 output_base[2] = { t, gamma };
+    for (unsigned i = 0; i < 2; i++)
+        for (unsigned j = 0; j < r; j++) {
+            u64 temp = 1;
+            for (unsigned kk = 0; kk < r; kk++) {
+                if (j == kk) continue;
+                temp = orc_mulmod(temp, qs[kk], output_base[i]);
+            }
+            bcm[i * r + j] = temp;
+        }
+
+    /* ---- decryption_rns, bfv_decryption.cuh:76-138 (q_amount == r here) ---- */
+    u64* c1 = c + (size_t)(r + 1) * n;
+    orc_forward_batch(c1, n, psi_tabs, r, r + 1, qs, mus, kbits, 1);                 /* :98  */
+    if (stage_out) memcpy(stage_out, c1, sizeof(u64) * (size_t)r * n);
+    orc_pointwise_batch(c1, c1, sk, n, r, r, qs, mus, kbits);                         /* :99-100 */
+    if (stage_out) memcpy(stage_out + (size_t)r * n, c1, sizeof(u64) * (size_t)r * n);
+    orc_inverse_batch(c1, n, psiinv_tabs, r, r + 1, qs, mus, kbits, 1);              /* :101 */
+    if (stage_out) memcpy(stage_out + (size_t)2 * r * n, c1, sizeof(u64) * (size_t)r * n);
+
+    for (size_t i = 0; i < (size_t)n * r; i++) {                   /* poly_add_xq_d, :13-23 (note `>`) */
+        u64 ra = c[i + (size_t)n * (r + 1)] + c[i];
+        if (ra > qs[i / n]) ra -= qs[i / n];
+        c[i + (size_t)n * (r + 1)] = ra;
+    }
+    for (size_t i = 0; i < (size_t)n * r; i++)                     /* poly_mul_int_xq_prodtgamma, :25-40 */
+        c1[i] = barrett128((u128)c1[i] * ptg[i / n], qs[i / n], mus[i / n], kbits[i / n]);
+    for (size_t i = 0; i < (size_t)n * r; i++)                     /* poly_mul_int_xq_invpq, :42-57 */
+        c1[i] = barrett128((u128)c1[i] * inv_punct[i / n], qs[i / n], mus[i / n], kbits[i / n]);
+
+    unsigned mask32 = (unsigned)(t - 1);                           /* fast_convert_array_kernel_t, poly_arithmetic.cuh:221-239 */
+    for (unsigned kk = 0; kk < n; kk++) {
+        u64 acc = 0;
+        for (unsigned i = 0; i < r; i++) {
+            u64 tmp = c1[kk + (size_t)i * n] * bcm[i];
+            tmp = tmp & mask32;
+            acc += tmp;
+        }
+        c[kk] = acc & mask32;
+    }
+    for (unsigned kk = 0; kk < n; kk++) {                          /* fast_convert_array_kernel_gamma, :241-256 */
+        u64 acc = 0;
+        for (unsigned i = 0; i < r; i++) {
+            u64 tmp = barrett128((u128)c1[kk + (size_t)i * n] * bcm[i + r], gamma, mu_gamma, gamma_bits);
+            acc = (acc + tmp) % gamma;
+        }
+        c[kk + n] = acc % gamma;
+    }
+    u64 mask = t - 1;
+    for (unsigned i = 0; i < n; i++)                               /* poly_mul_int_t -> mod_t, :128-142 */
+        c[i] = (c[i] * neg_inv[0]) & (unsigned)mask;
+    for (unsigned i = 0; i < n; i++)                               /* poly_mul_int -> barrett_int on gamma */
+        c[n + i] = barrett128((u128)c[n + i] * neg_inv[1], gamma, mu_gamma, gamma_bits);
+    u64* result = c + (size_t)n * (r - 1);                         /* dec_round_kernel, :258-268 */
+    for (unsigned i = 0; i < n; i++) {
+        u64 x0 = c[i], x1 = c[i + n];
+        if (x1 > gamma_div_2) result[i] = (x0 + (gamma - x1)) & mask;
+        else                  result[i] = (x0 - x1) & mask;
+    }
+    memcpy(out, result, sizeof(u64) * n);                          /* decryption_test.cu:376-377 */
+    free(psi_tabs); free(psiinv_tabs);
+    return 0;
+}
+
+/* -------------------------------------------------------- synthetic inputs */
+
+/* splitmix64, state x0 = seed, value = z mod q */
+void orc_splitmix_fill(u64* a, unsigned long count, u64 seed, u64 q)
+{
+    u64 x = seed;
+    for (unsigned long i = 0; i < count; i++) {
+        x += 0x9E3779B97F4A7C15ULL;
+        u64 z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        a[i] = z % q;
+    }
+}

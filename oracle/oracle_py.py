@@ -1,0 +1,204 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(), bench.py's
+cpu_baseline leg.  The product path (ntt-cuda_amd/) never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u64 = ctypes.c_ulonglong
+u64p = ctypes.POINTER(u64)
+u32p = ctypes.POINTER(ctypes.c_uint)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        L = _LIB
+        L.orc_bit_length.restype = ctypes.c_uint
+        L.orc_bit_length.argtypes = [u64]
+        for name in ("orc_mu",):
+            getattr(L, name).restype = u64
+        L.orc_mu.argtypes = [u64, ctypes.c_uint]
+        L.orc_mulmod.restype = u64
+        L.orc_mulmod.argtypes = [u64, u64, u64]
+        L.orc_modpow.restype = u64
+        L.orc_modpow.argtypes = [u64, u64, u64]
+        L.orc_modinv.restype = u64
+        L.orc_modinv.argtypes = [u64, u64]
+        L.orc_bitrev.restype = u64
+        L.orc_bitrev.argtypes = [u64, ctypes.c_int]
+        L.orc_barrett.restype = u64
+        L.orc_barrett.argtypes = [u64, u64, u64, u64, ctypes.c_uint]
+        L.orc_fill_table.restype = None
+        L.orc_fill_table.argtypes = [u64, u64, u64p, ctypes.c_uint]
+        L.orc_get_params.restype = ctypes.c_int
+        L.orc_get_params.argtypes = [u64, u64p, u64p, u64p, u64p, u32p]
+        L.orc_ct_stage.restype = None
+        L.orc_ct_stage.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint, u64, u64, ctypes.c_uint, u64p]
+        L.orc_gs_stage.restype = None
+        L.orc_gs_stage.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint, u64, u64, ctypes.c_uint, u64p]
+        L.orc_forward.restype = None
+        L.orc_forward.argtypes = [u64p, ctypes.c_uint, u64, u64, ctypes.c_uint, u64p]
+        L.orc_inverse.restype = None
+        L.orc_inverse.argtypes = [u64p, ctypes.c_uint, u64, u64, ctypes.c_uint, u64p]
+        for name in ("orc_forward_batch", "orc_inverse_batch"):
+            f = getattr(L, name)
+            f.restype = None
+            f.argtypes = [u64p, ctypes.c_uint, u64p, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, ctypes.c_int]
+        L.orc_pointwise.restype = None
+        L.orc_pointwise.argtypes = [u64p, u64p, ctypes.c_uint, u64, u64, ctypes.c_uint]
+        L.orc_pointwise_batch.restype = None
+        L.orc_pointwise_batch.argtypes = [u64p, u64p, u64p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p]
+        L.orc_pointwise_scalar.restype = None
+        L.orc_pointwise_scalar.argtypes = [u64p, u64, ctypes.c_uint, u64, u64, ctypes.c_uint]
+        L.orc_ref_polymul.restype = None
+        L.orc_ref_polymul.argtypes = [u64p, u64p, u64p, u64, ctypes.c_uint]
+        L.orc_bfv_decrypt.restype = ctypes.c_int
+        L.orc_bfv_decrypt.argtypes = [u64p, u64p, u64p, u64p, ctypes.c_uint, ctypes.c_uint, u64, u64, u64p, u64p]
+        L.orc_bfv_constants.restype = None
+        L.orc_bfv_constants.argtypes = [u64p, u64p, ctypes.c_uint, u64, u64, u64p, u64p, u64p, u64p, u64p, u64p]
+        L.orc_splitmix_fill.restype = None
+        L.orc_splitmix_fill.argtypes = [u64p, ctypes.c_ulong, u64, u64]
+    return _LIB
+
+
+def _p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _p32(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+class Params:
+    """Per-prime parameters derived the reference's way (bit length, mu, psi^-1, both tables)."""
+
+    def __init__(self, n, qs, psis, tables=True):
+        L = lib()
+        self.n = int(n)
+        self.q = np.array(qs, dtype=np.uint64)
+        self.psi = np.array(psis, dtype=np.uint64)
+        P = len(self.q)
+        self.k = np.array([L.orc_bit_length(int(q)) for q in self.q], dtype=np.uint32)
+        self.mu = np.array([L.orc_mu(int(q), int(k)) for q, k in zip(self.q, self.k)], dtype=np.uint64)
+        self.psiinv = np.array([L.orc_modinv(int(p), int(q)) for p, q in zip(self.psi, self.q)], dtype=np.uint64)
+        if tables:
+            self.psi_tabs = np.empty((P, self.n), dtype=np.uint64)
+            self.psiinv_tabs = np.empty((P, self.n), dtype=np.uint64)
+            for i in range(P):
+                L.orc_fill_table(int(self.psi[i]), int(self.q[i]), _p(self.psi_tabs[i]), self.n)
+                L.orc_fill_table(int(self.psiinv[i]), int(self.q[i]), _p(self.psiinv_tabs[i]), self.n)
+
+
+def splitmix(count, seed, q):
+    a = np.empty(int(count), dtype=np.uint64)
+    lib().orc_splitmix_fill(_p(a), int(count), int(seed), int(q))
+    return a
+
+
+def synth_batch(n, num, qs, seed_base=1):
+    """polynomial y = splitmix64(seed = seed_base + y) mod q[y % P]."""
+    out = np.empty((num, n), dtype=np.uint64)
+    P = len(qs)
+    for y in range(num):
+        lib().orc_splitmix_fill(_p(out[y]), n, seed_base + y, int(qs[y % P]))
+    return out
+
+
+def forward(a, prm, idx=0):
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    lib().orc_forward(_p(a), prm.n, int(prm.q[idx]), int(prm.mu[idx]), int(prm.k[idx]), _p(prm.psi_tabs[idx]))
+    return a
+
+
+def inverse(a, prm, idx=0):
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    lib().orc_inverse(_p(a), prm.n, int(prm.q[idx]), int(prm.mu[idx]), int(prm.k[idx]), _p(prm.psiinv_tabs[idx]))
+    return a
+
+
+def forward_batch(a, prm, division=None, threads=1):
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    num = a.size // prm.n
+    division = division or len(prm.q)
+    lib().orc_forward_batch(_p(a), prm.n, _p(prm.psi_tabs), num, division, _p(prm.q), _p(prm.mu), _p32(prm.k), threads)
+    return a
+
+
+def inverse_batch(a, prm, division=None, threads=1):
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    num = a.size // prm.n
+    division = division or len(prm.q)
+    lib().orc_inverse_batch(_p(a), prm.n, _p(prm.psiinv_tabs), num, division, _p(prm.q), _p(prm.mu), _p32(prm.k), threads)
+    return a
+
+
+def pointwise_batch(a, b, prm, division=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    c = np.empty_like(a)
+    num = a.size // prm.n
+    division = division or len(prm.q)
+    lib().orc_pointwise_batch(_p(c), _p(a), _p(b), prm.n, num, division, _p(prm.q), _p(prm.mu), _p32(prm.k))
+    return c
+
+
+def pointwise_scalar(a, b, prm, idx=0):
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    lib().orc_pointwise_scalar(_p(a), int(b), a.size, int(prm.q[idx]), int(prm.mu[idx]), int(prm.k[idx]))
+    return a
+
+
+def ref_polymul(a, b, q):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    d = np.empty_like(a)
+    lib().orc_ref_polymul(_p(a), _p(b), _p(d), int(q), a.size)
+    return d
+
+
+def bfv_decrypt(c, sk, qs, psis, n, t, gamma, want_stages=False):
+    c = np.ascontiguousarray(c, dtype=np.uint64).copy()
+    sk = np.ascontiguousarray(sk, dtype=np.uint64)
+    qs = np.array(qs, dtype=np.uint64)
+    psis = np.array(psis, dtype=np.uint64)
+    r = len(qs) - 1
+    out = np.empty(n, dtype=np.uint64)
+    stages = np.empty((3, r * n), dtype=np.uint64) if want_stages else None
+    rc = lib().orc_bfv_decrypt(_p(c), _p(sk), _p(qs), _p(psis), len(qs), n, int(t), int(gamma), _p(out),
+                               _p(stages) if want_stages else None)
+    assert rc == 0
+    return (out, stages) if want_stages else out
+
+
+def bfv_constants(qs, psis, t, gamma):
+    qs = np.array(qs, dtype=np.uint64)
+    psis = np.array(psis, dtype=np.uint64)
+    R = len(qs)
+    r = R - 1
+    psiinv = np.empty(R, dtype=np.uint64)
+    ipq = np.empty(r, dtype=np.uint64)
+    neg = np.empty(2, dtype=np.uint64)
+    ptg = np.empty(r, dtype=np.uint64)
+    iql = np.empty(r, dtype=np.uint64)
+    qdt = np.empty(R, dtype=np.uint64)
+    lib().orc_bfv_constants(_p(qs), _p(psis), R, int(t), int(gamma), _p(psiinv), _p(ipq), _p(neg), _p(ptg), _p(iql), _p(qdt))
+    return dict(psiinv=psiinv, inv_punctured_q=ipq, neg_inv_q_mod_t_gamma=neg, prod_t_gamma_mod_q=ptg,
+                inv_q_last_mod_q=iql, qi_div_t=qdt)
