@@ -1,0 +1,144 @@
+/*
+ * mi355ntt.h -- C ABI of the MI355X-native 60-bit NTT engine (libmi355ntt.so).
+ *
+ * This is the drop-in boundary for the NTT hot path of ozgunozerk/NTT-Cuda.  The reference has no
+ * FFI layer: its "operator API" is a set of free functions/kernels in headers that every program
+ * textually includes (BFV_Scheme/ntt_60bit.cuh, poly_arithmetic.cuh).  Each entry point below names
+ * the reference interface it replaces (paths relative to /root/reference/BFV_Scheme/).
+ *
+ * Conventions:
+ *   - All data pointers are DEVICE pointers to unsigned 64-bit words; plain pointers and sizes only.
+ *   - Transforms are in place.  Inputs/outputs are canonical residues in [0, q).
+ *   - Forward output is in bit-reversed order; inverse input is bit-reversed, its output is natural
+ *     order and already scaled by n^-1 (as the reference's halving butterflies produce).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All calls are
+ *     asynchronous on that stream; nothing here synchronises or allocates after context creation.
+ *   - Every function returns MI355NTT_OK (0) or a negative MI355NTT_E* code.  (The reference reports
+ *     no errors: unsupported n silently launches nothing, ntt_60bit.cuh:344-347.)
+ *   - No global mutable state: the reference's __constant__ q_cons/q_bit_cons/mu_cons
+ *     (ntt_60bit.cuh:8-10) live in an immutable context object, usable from any host thread.
+ *   - Limits: n a power of two, 2^11 <= n <= 2^16 for the transforms (the reference dispatches
+ *     2^11..2^15, ntt_60bit.cuh:316-347); <= 16 primes per context; q < 2^62 odd, q = 1 (mod 2n).
+ */
+#ifndef MI355NTT_H
+#define MI355NTT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned long long mi355ntt_u64;
+typedef struct mi355ntt_ctx mi355ntt_ctx;
+typedef void* mi355ntt_stream; /* hipStream_t */
+
+enum {
+    MI355NTT_OK = 0,
+    MI355NTT_EINVAL = -1,      /* null pointer, bad count, num/division inconsistent                */
+    MI355NTT_EUNSUPPORTED = -2, /* n not a supported power of two, too many primes, q out of range */
+    MI355NTT_EHIP = -3,        /* a HIP runtime call failed (see mi355ntt_last_hip_error)           */
+    MI355NTT_ENOMEM = -4,
+    MI355NTT_EPARAM = -5       /* psi is not a primitive 2n-th root of unity mod q, q even, ...     */
+};
+
+#define MI355NTT_MAX_PRIMES 16 /* __constant__ arrays are [16], ntt_60bit.cuh:8-10 */
+
+const char* mi355ntt_strerror(int code);
+int mi355ntt_last_hip_error(void);         /* hipError_t of the last failing HIP call on this thread */
+const char* mi355ntt_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-only parameter helpers (no GPU needed).  Replace helper.h:8-70, parameter.h:5-20 and the
+ * mu / bit-length bootstrap at 60bit_ntt_test.cu:47-49, demo.cu:69,157-165.
+ * ---------------------------------------------------------------------------------------------- */
+unsigned     mi355ntt_bit_length(mi355ntt_u64 q);                                   /* demo.cu:69 */
+mi355ntt_u64 mi355ntt_barrett_mu(mi355ntt_u64 q, unsigned bit_length);              /* 60bit_ntt_test.cu:47-49 */
+mi355ntt_u64 mi355ntt_mulmod(mi355ntt_u64 a, mi355ntt_u64 b, mi355ntt_u64 m);       /* host64x2 + operator%, uint128.h:278-341 */
+mi355ntt_u64 mi355ntt_modpow(mi355ntt_u64 a, mi355ntt_u64 e, mi355ntt_u64 m);       /* modpow128, helper.h:8-28 */
+mi355ntt_u64 mi355ntt_modinv(mi355ntt_u64 a, mi355ntt_u64 q);                       /* modinv128, helper.h:52-56 */
+mi355ntt_u64 mi355ntt_bit_reverse(mi355ntt_u64 a, int bits);                        /* bitReverse, helper.h:58-70 */
+/* fillTablePsi128 (parameter.h:5-12): psi_table[i] = psi^bitrev(i), psiinv_table[i] = psiinv^bitrev(i);
+ * either output may be NULL. */
+int mi355ntt_fill_tables(mi355ntt_u64 psi, mi355ntt_u64 psiinv, mi355ntt_u64 q, unsigned n,
+                         mi355ntt_u64* host_psi_table, mi355ntt_u64* host_psiinv_table);
+/* getParams (parameter.h:31-79): the reference's hard-coded single-prime sets, n in {2048..32768}. */
+int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt_u64* psiinv,
+                        mi355ntt_u64* ninv, unsigned* bit_length);
+
+/* ------------------------------------------------------------------------------------------------
+ * Context: replaces the caller-side bootstrap (demo.cu:62-196: bit lengths, mu, psi^-1, psi tables,
+ * cudaMemcpyToSymbol of q_cons/q_bit_cons/mu_cons, table upload).  Immutable after creation.
+ * ---------------------------------------------------------------------------------------------- */
+int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
+                        const mi355ntt_u64* q, const mi355ntt_u64* psi, int device);
+int mi355ntt_ctx_destroy(mi355ntt_ctx* ctx);
+unsigned mi355ntt_ctx_n(const mi355ntt_ctx* ctx);
+unsigned mi355ntt_ctx_num_primes(const mi355ntt_ctx* ctx);
+/* per-prime derived parameters; any out pointer may be NULL */
+int mi355ntt_ctx_prime(const mi355ntt_ctx* ctx, unsigned prime_idx, mi355ntt_u64* q, mi355ntt_u64* mu,
+                       unsigned* bit_length, mi355ntt_u64* psi, mi355ntt_u64* psiinv);
+/* device pointers to the reference-format tables, [num_primes][n] contiguous (demo.cu:188-196) */
+const mi355ntt_u64* mi355ntt_ctx_psi_tables(const mi355ntt_ctx* ctx);
+const mi355ntt_u64* mi355ntt_ctx_psiinv_tables(const mi355ntt_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Transforms on a context
+ * ---------------------------------------------------------------------------------------------- */
+/* forwardNTT (ntt_60bit.cuh:314-348): one polynomial, prime prime_idx */
+int mi355ntt_forward(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream stream);
+/* inverseNTT (ntt_60bit.cuh:350-386) */
+int mi355ntt_inverse(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream stream);
+/* forwardNTTdouble (ntt_60bit.cuh:267-312): two polynomials, same prime, on two streams */
+int mi355ntt_forward_double(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, mi355ntt_u64* d_b, unsigned prime_idx,
+                            mi355ntt_stream stream1, mi355ntt_stream stream2);
+/* forwardNTT_batch / inverseNTT_batch (ntt_60bit.cuh:608-697): num polynomials of n words at
+ * d_a + y*n; polynomial y uses prime (y % division) (ntt_60bit.cuh:391,404,422). 1 <= division <= num_primes. */
+int mi355ntt_forward_batch(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned num, unsigned division,
+                           mi355ntt_stream stream);
+int mi355ntt_inverse_batch(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned num, unsigned division,
+                           mi355ntt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pointwise products on a context
+ * ---------------------------------------------------------------------------------------------- */
+/* barrett (poly_arithmetic.cuh:9), barrett_batch (:36) when d_c == d_a, barrett_batch_3param (:68)
+ * otherwise: d_c[y*n+x] = d_a[y*n+x] * d_b[y*n+x] mod q[y % division]. */
+int mi355ntt_pointwise_mul(const mi355ntt_ctx* ctx, mi355ntt_u64* d_c, const mi355ntt_u64* d_a,
+                           const mi355ntt_u64* d_b, unsigned num, unsigned division, mi355ntt_stream stream);
+/* barrett_int (poly_arithmetic.cuh:100) / poly_mul_int (:317): d_a[i] = d_a[i] * b mod q[prime_idx], one polynomial */
+int mi355ntt_pointwise_mul_scalar(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, mi355ntt_u64 b,
+                                  unsigned prime_idx, mi355ntt_stream stream);
+/* The composition the BFV drivers run: forwardNTT_batch -> barrett_batch -> inverseNTT_batch
+ * (bfv_encryption.cuh:268-271, bfv_decryption.cuh:98-101, half_poly_mul_device poly_arithmetic.cuh:303-310),
+ * fused into one pass over d_a: d_a[y] = INTT( NTT(d_a[y]) (.) d_bhat[y] ).  d_bhat is in the NTT domain. */
+int mi355ntt_polymul_batch(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, const mi355ntt_u64* d_bhat,
+                           unsigned num, unsigned division, mi355ntt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Raw-parameter entry points: signature-compatible with the reference (caller supplies q, mu,
+ * bit_length and reference-format device tables).  These follow Algorithm 7 (singleBarrett,
+ * ntt_60bit.cuh:44-61) literally with the caller's mu/bit_length.
+ * ---------------------------------------------------------------------------------------------- */
+int mi355ntt_forward_raw(mi355ntt_u64* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q, mi355ntt_u64 mu,
+                         int bit_length, const mi355ntt_u64* d_psi_table);                        /* forwardNTT :314 */
+int mi355ntt_inverse_raw(mi355ntt_u64* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q, mi355ntt_u64 mu,
+                         int bit_length, const mi355ntt_u64* d_psiinv_table);                     /* inverseNTT :350 */
+/* q/mu/bit_length: HOST arrays of `division` entries standing in for q_cons/mu_cons/q_bit_cons */
+int mi355ntt_forward_batch_raw(mi355ntt_u64* d_a, unsigned n, const mi355ntt_u64* d_psi_tables, unsigned num,
+                               unsigned division, const mi355ntt_u64* q, const mi355ntt_u64* mu,
+                               const unsigned* bit_length, mi355ntt_stream stream);               /* :608 */
+int mi355ntt_inverse_batch_raw(mi355ntt_u64* d_a, unsigned n, const mi355ntt_u64* d_psiinv_tables, unsigned num,
+                               unsigned division, const mi355ntt_u64* q, const mi355ntt_u64* mu,
+                               const unsigned* bit_length, mi355ntt_stream stream);               /* :652 */
+int mi355ntt_barrett_raw(mi355ntt_u64* d_c, const mi355ntt_u64* d_a, const mi355ntt_u64* d_b, unsigned n,
+                         unsigned num, unsigned division, const mi355ntt_u64* q, const mi355ntt_u64* mu,
+                         const unsigned* bit_length, mi355ntt_stream stream);     /* barrett*, poly_arithmetic.cuh:9-98 */
+int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_u64 q, mi355ntt_u64 mu,
+                             int bit_length, mi355ntt_stream stream);                             /* barrett_int :100 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355NTT_H */

@@ -1,0 +1,53 @@
+// kernels.hpp -- host-callable launchers shared between the C ABI and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hostparams.hpp"
+
+namespace mi355ntt {
+
+constexpr unsigned kMaxPrimes = 16;
+
+// Per-launch copy of the moduli: replaces the reference's __constant__ q_cons / mu_cons / q_bit_cons
+// (ntt_60bit.cuh:8-10).  Passed by value in the kernel argument segment (SGPR-resident).
+struct ModSet {
+    u64 q[kMaxPrimes];
+    u64 mu[kMaxPrimes];
+    unsigned k[kMaxPrimes];
+};
+
+// ---- literal stage-per-launch kernels (kernels_compat.hip) ----
+hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
+                                hipStream_t s);
+hipError_t compat_inverse_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
+                                hipStream_t s);
+hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
+                            const ModSet& m, hipStream_t s);
+hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s);
+
+// ---- throughput kernels (kernels_fast.hip) ----
+// Device tables private to the fast path.  Built once per context from the reference-format tables.
+struct FastTables {
+    unsigned n = 0, log_n = 0, num_primes = 0;
+    PrimeParams prime[kMaxPrimes];
+    ModSet mods;
+    // [P][n] pairs {w, floor(w*2^64/q)}: twiddle and its Shoup companion, interleaved so one 16-byte
+    // load fetches both.  Same indexing as the reference tables (entry length+p for stage `length`).
+    u64* d_fwd = nullptr;   // psi^bitrev(i)
+    u64* d_inv = nullptr;   // psi^-bitrev(i); entry 1 additionally carries the n^-1 scaling (see kernels_fast.hip)
+    u64* d_ninv = nullptr;  // [P] pairs {n^-1, shoup(n^-1)}
+    const u64* d_psi = nullptr;     // reference-format tables owned by the context (fallback path)
+    const u64* d_psiinv = nullptr;
+};
+
+hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
+                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv);
+void fast_tables_destroy(FastTables* t);
+// polynomial y of the batch uses prime (prime_base + y % division)
+hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);
+hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);
+hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u64* d_b, unsigned num, unsigned division,
+                          hipStream_t s);
+hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s);
+
+}  // namespace mi355ntt

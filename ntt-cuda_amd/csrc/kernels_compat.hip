@@ -1,0 +1,121 @@
+// kernels_compat.hip -- literal, stage-per-launch kernels behind the raw-parameter entry points.
+//
+// These follow the reference's arithmetic step by step (Algorithm 7 with the caller's mu/bit_length,
+// canonical residues after every stage, halving in every GS stage) so that a caller who brings its
+// own tables and Barrett constants gets exactly what ntt_60bit.cuh would have produced.  They are the
+// device-side ground truth the fast kernels in kernels_fast.hip are checked against; they are not the
+// throughput path.
+//
+// Reference counterparts (BFV_Scheme/): CTBasedNTTInner(_batch) ntt_60bit.cuh:192-223,527-561;
+// GSBasedINTTInner(_batch) :225-265,563-606; barrett* poly_arithmetic.cuh:9-126.
+#include "kernels.hpp"
+#include "modarith.cuh"
+
+namespace mi355ntt {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// One CT stage over a batch.  blockIdx.y = polynomial, modulus index = y % division
+// (ntt_60bit.cuh:391-394), data offset y*n (:404), table offset index*n (:422).
+__global__ void __launch_bounds__(kBlock) ct_stage_kernel(u64* __restrict__ a, const u64* __restrict__ tabs, unsigned n,
+                                                          unsigned length, unsigned division, ModSet m)
+{
+    unsigned y = blockIdx.y;
+    unsigned idx = y % division;
+    u64 q = m.q[idx], mu = m.mu[idx];
+    u32 k = m.k[idx];
+    unsigned g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n / 2) return;
+    unsigned step = (n / length) / 2;
+    unsigned p = g / step;
+    unsigned j = p * step * 2 + (g % step);
+    u64* poly = a + (size_t)y * n;
+    u64 psi = tabs[(size_t)idx * n + length + p];
+    u64 U = poly[j];
+    u64 V = barrett_mul(poly[j + step], psi, q, mu, k);
+    poly[j] = add_mod(U, V, q);
+    poly[j + step] = sub_mod(U, V, q);
+}
+
+// One GS stage with the n^-1 halving (ntt_60bit.cuh:225-265)
+__global__ void __launch_bounds__(kBlock) gs_stage_kernel(u64* __restrict__ a, const u64* __restrict__ tabs, unsigned n,
+                                                          unsigned length, unsigned division, ModSet m)
+{
+    unsigned y = blockIdx.y;
+    unsigned idx = y % division;
+    u64 q = m.q[idx], mu = m.mu[idx];
+    u32 k = m.k[idx];
+    unsigned g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n / 2) return;
+    unsigned step = (n / length) / 2;
+    unsigned p = g / step;
+    unsigned j = p * step * 2 + (g % step);
+    u64* poly = a + (size_t)y * n;
+    u64 psiinv = tabs[(size_t)idx * n + length + p];
+    u64 q2 = (q + 1) >> 1;
+    u64 U = poly[j];
+    u64 V = poly[j + step];
+    poly[j] = half_mod(add_mod(U, V, q), q2);
+    u64 d = barrett_mul(sub_mod(U, V, q), psiinv, q, mu, k);
+    poly[j + step] = half_mod(d, q2);
+}
+
+// c[i] = a[i] * b[i] mod q[y % division]   (barrett / barrett_batch / barrett_batch_3param)
+__global__ void __launch_bounds__(kBlock) pointwise_kernel(u64* __restrict__ c, const u64* __restrict__ a,
+                                                           const u64* __restrict__ b, unsigned n, unsigned division, ModSet m)
+{
+    unsigned y = blockIdx.y;
+    unsigned idx = y % division;
+    u64 q = m.q[idx], mu = m.mu[idx];
+    u32 k = m.k[idx];
+    unsigned x = blockIdx.x * kBlock + threadIdx.x;
+    if (x >= n) return;
+    size_t i = (size_t)y * n + x;
+    c[i] = barrett_mul(a[i], b[i], q, mu, k);
+}
+
+// a[i] = a[i] * b mod q   (barrett_int)
+__global__ void __launch_bounds__(kBlock) pointwise_scalar_kernel(u64* __restrict__ a, u64 b, unsigned n, u64 q, u64 mu, u32 k)
+{
+    unsigned x = blockIdx.x * kBlock + threadIdx.x;
+    if (x >= n) return;
+    a[x] = barrett_mul(a[x], b, q, mu, k);
+}
+
+}  // namespace
+
+hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
+                                hipStream_t s)
+{
+    dim3 grid((n / 2 + kBlock - 1) / kBlock, num);
+    for (unsigned length = 1; length < n; length *= 2)
+        ct_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    return hipGetLastError();
+}
+
+hipError_t compat_inverse_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
+                                hipStream_t s)
+{
+    dim3 grid((n / 2 + kBlock - 1) / kBlock, num);
+    for (unsigned length = n / 2; length >= 1; length /= 2)
+        gs_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    return hipGetLastError();
+}
+
+hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
+                            const ModSet& m, hipStream_t s)
+{
+    dim3 grid((n + kBlock - 1) / kBlock, num);
+    pointwise_kernel<<<grid, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, m);
+    return hipGetLastError();
+}
+
+hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s)
+{
+    pointwise_scalar_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(d_a, b, n, q, mu, k);
+    return hipGetLastError();
+}
+
+}  // namespace mi355ntt

@@ -1,0 +1,351 @@
+"""ntt_cuda_amd -- Python plumbing over the MI355X-native NTT engine's C ABI (libmi355ntt.so).
+
+The product is the HIP library; this module only loads it through ctypes, mirrors the reference's host
+call surface (BFV_Scheme/ntt_60bit.cuh:267-386,608-697 and poly_arithmetic.cuh:9-126,277-310 of
+ozgunozerk/NTT-Cuda) with the same names and argument meaning, and uses torch for device memory and
+streams.  There is NO CPU fallback: if the library is missing, import of the native handle fails loudly.
+
+Polynomials are torch.int64 CUDA tensors holding the bit patterns of unsigned 64-bit residues.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG_DIR)                  # ntt-cuda_amd/
+LIB_PATH = os.path.join(_ROOT, "libmi355ntt.so")
+
+u64 = ctypes.c_ulonglong
+u64p = ctypes.POINTER(u64)
+u32p = ctypes.POINTER(ctypes.c_uint)
+vp = ctypes.c_void_p
+
+OK = 0
+EINVAL, EUNSUPPORTED, EHIP, ENOMEM, EPARAM = -1, -2, -3, -4, -5
+
+# name -> (restype, argtypes); mirrors include/mi355ntt.h one to one
+_SIGNATURES = {
+    "mi355ntt_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "mi355ntt_last_hip_error": (ctypes.c_int, []),
+    "mi355ntt_version": (ctypes.c_char_p, []),
+    "mi355ntt_bit_length": (ctypes.c_uint, [u64]),
+    "mi355ntt_barrett_mu": (u64, [u64, ctypes.c_uint]),
+    "mi355ntt_mulmod": (u64, [u64, u64, u64]),
+    "mi355ntt_modpow": (u64, [u64, u64, u64]),
+    "mi355ntt_modinv": (u64, [u64, u64]),
+    "mi355ntt_bit_reverse": (u64, [u64, ctypes.c_int]),
+    "mi355ntt_fill_tables": (ctypes.c_int, [u64, u64, u64, ctypes.c_uint, u64p, u64p]),
+    "mi355ntt_get_params": (ctypes.c_int, [ctypes.c_uint, u64p, u64p, u64p, u64p, u32p]),
+    "mi355ntt_ctx_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, ctypes.c_int]),
+    "mi355ntt_ctx_destroy": (ctypes.c_int, [vp]),
+    "mi355ntt_ctx_n": (ctypes.c_uint, [vp]),
+    "mi355ntt_ctx_num_primes": (ctypes.c_uint, [vp]),
+    "mi355ntt_ctx_prime": (ctypes.c_int, [vp, ctypes.c_uint, u64p, u64p, u32p, u64p, u64p]),
+    "mi355ntt_ctx_psi_tables": (vp, [vp]),
+    "mi355ntt_ctx_psiinv_tables": (vp, [vp]),
+    "mi355ntt_forward": (ctypes.c_int, [vp, vp, ctypes.c_uint, vp]),
+    "mi355ntt_inverse": (ctypes.c_int, [vp, vp, ctypes.c_uint, vp]),
+    "mi355ntt_forward_double": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, vp, vp]),
+    "mi355ntt_forward_batch": (ctypes.c_int, [vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_inverse_batch": (ctypes.c_int, [vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_pointwise_mul": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_pointwise_mul_scalar": (ctypes.c_int, [vp, vp, u64, ctypes.c_uint, vp]),
+    "mi355ntt_polymul_batch": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_forward_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, u64, u64, ctypes.c_int, vp]),
+    "mi355ntt_inverse_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, u64, u64, ctypes.c_int, vp]),
+    "mi355ntt_forward_batch_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, vp]),
+    "mi355ntt_inverse_batch_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, vp]),
+    "mi355ntt_barrett_raw": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, vp]),
+    "mi355ntt_barrett_int_raw": (ctypes.c_int, [vp, u64, ctypes.c_uint, u64, u64, ctypes.c_int, vp]),
+}
+
+_lib = None
+
+
+class NTTError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().mi355ntt_strerror(code).decode()
+        if code == EHIP:
+            msg += " (hipError_t %d)" % lib().mi355ntt_last_hip_error()
+        super().__init__("%s: %s [%d]" % (where, msg, code))
+
+
+def build(force=False):
+    """Compile libmi355ntt.so for gfx950 in tree (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _ROOT, "-s", "-j4"])
+    return LIB_PATH
+
+
+def lib():
+    """The native library handle.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmi355ntt.so not found at %s -- run __graft_entry__.build() / make -C ntt-cuda_amd" % LIB_PATH)
+        # torch bundles its own HIP runtime (SONAME libamdhip64.so.7).  Load it first so that this library
+        # binds to the same runtime instance: two HIP runtimes in one process do not share devices/streams.
+        import torch  # noqa: F401
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(L, name)       # AttributeError if the ABI drifted from the header
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(code, where):
+    if code != OK:
+        raise NTTError(code, where)
+
+
+def _np_u64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or raw int address)."""
+    if isinstance(t, int):
+        return vp(t)
+    assert t.is_cuda and t.is_contiguous() and t.element_size() == 8, "need a contiguous 64-bit CUDA tensor"
+    return vp(t.data_ptr())
+
+
+def _stream(stream=None):
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream()
+    if isinstance(stream, int):
+        return vp(stream)
+    return vp(stream.cuda_stream)
+
+
+# --------------------------------------------------------------------------- host-only helpers
+def bit_length(q):
+    return int(lib().mi355ntt_bit_length(int(q)))
+
+
+def barrett_mu(q, bits):
+    return int(lib().mi355ntt_barrett_mu(int(q), int(bits)))
+
+
+def modpow128(a, b, mod):
+    """helper.h:8-28"""
+    return int(lib().mi355ntt_modpow(int(a), int(b), int(mod)))
+
+
+def modinv128(a, q):
+    """helper.h:52-56"""
+    return int(lib().mi355ntt_modinv(int(a), int(q)))
+
+
+def bitReverse(a, bit_length_):
+    """helper.h:58-70"""
+    return int(lib().mi355ntt_bit_reverse(int(a), int(bit_length_)))
+
+
+def fillTablePsi128(psi, q, psiinv, n):
+    """parameter.h:5-12; returns (psiTable, psiinvTable) as numpy uint64 arrays."""
+    tp = np.empty(n, dtype=np.uint64)
+    ti = np.empty(n, dtype=np.uint64)
+    _check(lib().mi355ntt_fill_tables(int(psi), int(psiinv), int(q), int(n), tp.ctypes.data_as(u64p), ti.ctypes.data_as(u64p)),
+           "fillTablePsi128")
+    return tp, ti
+
+
+def getParams(n):
+    """parameter.h:31-79; returns (q, psi, psiinv, ninv, q_bit)."""
+    q, psi, psiinv, ninv = u64(), u64(), u64(), u64()
+    bits = ctypes.c_uint()
+    _check(lib().mi355ntt_get_params(int(n), ctypes.byref(q), ctypes.byref(psi), ctypes.byref(psiinv), ctypes.byref(ninv),
+                                     ctypes.byref(bits)), "getParams")
+    return q.value, psi.value, psiinv.value, ninv.value, bits.value
+
+
+# --------------------------------------------------------------------------- tensors
+def to_device(a, device="cuda:0"):
+    """numpy uint64 array -> torch.int64 CUDA tensor with the same bits."""
+    import torch
+    return torch.from_numpy(_np_u64(a).view(np.int64)).to(device)
+
+
+def to_host(t):
+    """torch.int64 CUDA tensor -> numpy uint64 array."""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+# --------------------------------------------------------------------------- context API
+class NTTContext:
+    """Immutable per-(n, primes) state: replaces the bootstrap at demo.cu:62-196 and the __constant__
+    q_cons/q_bit_cons/mu_cons symbols (ntt_60bit.cuh:8-10)."""
+
+    def __init__(self, n, q, psi, device=0):
+        self._h = vp()
+        qs, ps = _np_u64(np.atleast_1d(q)), _np_u64(np.atleast_1d(psi))
+        assert qs.size == ps.size
+        _check(lib().mi355ntt_ctx_create(ctypes.byref(self._h), int(n), int(qs.size), qs.ctypes.data_as(u64p),
+                                         ps.ctypes.data_as(u64p), int(device)), "mi355ntt_ctx_create")
+        self.n = int(n)
+        self.num_primes = int(qs.size)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mi355ntt_ctx_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prime(self, i):
+        q, mu, psi, psiinv = u64(), u64(), u64(), u64()
+        bits = ctypes.c_uint()
+        _check(lib().mi355ntt_ctx_prime(self._h, int(i), ctypes.byref(q), ctypes.byref(mu), ctypes.byref(bits), ctypes.byref(psi),
+                                        ctypes.byref(psiinv)), "mi355ntt_ctx_prime")
+        return dict(q=q.value, mu=mu.value, bit_length=bits.value, psi=psi.value, psiinv=psiinv.value)
+
+    @property
+    def psi_tables_ptr(self):
+        return int(lib().mi355ntt_ctx_psi_tables(self._h) or 0)
+
+    @property
+    def psiinv_tables_ptr(self):
+        return int(lib().mi355ntt_ctx_psiinv_tables(self._h) or 0)
+
+    # forwardNTT / inverseNTT (ntt_60bit.cuh:314,350)
+    def forward(self, a, prime_idx=0, stream=None):
+        _check(lib().mi355ntt_forward(self._h, _ptr(a), int(prime_idx), _stream(stream)), "mi355ntt_forward")
+
+    def inverse(self, a, prime_idx=0, stream=None):
+        _check(lib().mi355ntt_inverse(self._h, _ptr(a), int(prime_idx), _stream(stream)), "mi355ntt_inverse")
+
+    def forward_double(self, a, b, prime_idx=0, stream1=None, stream2=None):
+        _check(lib().mi355ntt_forward_double(self._h, _ptr(a), _ptr(b), int(prime_idx), _stream(stream1), _stream(stream2)),
+               "mi355ntt_forward_double")
+
+    # forwardNTT_batch / inverseNTT_batch (ntt_60bit.cuh:608,652)
+    def forward_batch(self, a, num, division=None, stream=None):
+        _check(lib().mi355ntt_forward_batch(self._h, _ptr(a), int(num), int(division or self.num_primes), _stream(stream)),
+               "mi355ntt_forward_batch")
+
+    def inverse_batch(self, a, num, division=None, stream=None):
+        _check(lib().mi355ntt_inverse_batch(self._h, _ptr(a), int(num), int(division or self.num_primes), _stream(stream)),
+               "mi355ntt_inverse_batch")
+
+    # barrett / barrett_batch / barrett_batch_3param (poly_arithmetic.cuh:9-98)
+    def pointwise_mul(self, c, a, b, num, division=None, stream=None):
+        _check(lib().mi355ntt_pointwise_mul(self._h, _ptr(c), _ptr(a), _ptr(b), int(num), int(division or self.num_primes),
+                                            _stream(stream)), "mi355ntt_pointwise_mul")
+
+    # barrett_int (poly_arithmetic.cuh:100)
+    def pointwise_mul_scalar(self, a, b, prime_idx=0, stream=None):
+        _check(lib().mi355ntt_pointwise_mul_scalar(self._h, _ptr(a), int(b), int(prime_idx), _stream(stream)),
+               "mi355ntt_pointwise_mul_scalar")
+
+    # forwardNTT_batch -> barrett_batch -> inverseNTT_batch (bfv_encryption.cuh:268-271), fused
+    def polymul_batch(self, a, bhat, num, division=None, stream=None):
+        _check(lib().mi355ntt_polymul_batch(self._h, _ptr(a), _ptr(bhat), int(num), int(division or self.num_primes),
+                                            _stream(stream)), "mi355ntt_polymul_batch")
+
+
+# --------------------------------------------------------------------------- reference-named raw API
+def forwardNTT(device_a, n, stream, q, mu, bit_length_, psi_powers):
+    """ntt_60bit.cuh:314 -- same argument order; psi_powers is a device tensor in the reference table format."""
+    _check(lib().mi355ntt_forward_raw(_ptr(device_a), int(n), _stream(stream), int(q), int(mu), int(bit_length_),
+                                      _ptr(psi_powers)), "forwardNTT")
+
+
+def inverseNTT(device_a, n, stream, q, mu, bit_length_, psiinv_powers):
+    """ntt_60bit.cuh:350"""
+    _check(lib().mi355ntt_inverse_raw(_ptr(device_a), int(n), _stream(stream), int(q), int(mu), int(bit_length_),
+                                      _ptr(psiinv_powers)), "inverseNTT")
+
+
+def forwardNTTdouble(device_a, device_b, n, stream1, stream2, q, mu, bit_length_, psi_powers):
+    """ntt_60bit.cuh:267"""
+    forwardNTT(device_a, n, stream1, q, mu, bit_length_, psi_powers)
+    forwardNTT(device_b, n, stream2, q, mu, bit_length_, psi_powers)
+
+
+class Moduli:
+    """Stand-in for the __constant__ q_cons / mu_cons / q_bit_cons the batch kernels read (ntt_60bit.cuh:8-10)."""
+
+    def __init__(self, q, mu=None, bits=None):
+        self.q = _np_u64(np.atleast_1d(q))
+        self.bits = np.ascontiguousarray(bits if bits is not None else [bit_length(x) for x in self.q], dtype=np.uint32)
+        self.mu = _np_u64(mu if mu is not None else [barrett_mu(x, k) for x, k in zip(self.q, self.bits)])
+
+    def args(self):
+        return self.q.ctypes.data_as(u64p), self.mu.ctypes.data_as(u64p), self.bits.ctypes.data_as(u32p)
+
+
+def forwardNTT_batch(device_a, n, psi_powers, num, division, moduli, stream=None):
+    """ntt_60bit.cuh:608 (+ the moduli the reference reads from __constant__ memory)"""
+    _check(lib().mi355ntt_forward_batch_raw(_ptr(device_a), int(n), _ptr(psi_powers), int(num), int(division), *moduli.args(),
+                                            _stream(stream)), "forwardNTT_batch")
+
+
+def inverseNTT_batch(device_a, n, psiinv_powers, num, division, moduli, stream=None):
+    """ntt_60bit.cuh:652"""
+    _check(lib().mi355ntt_inverse_batch_raw(_ptr(device_a), int(n), _ptr(psiinv_powers), int(num), int(division), *moduli.args(),
+                                            _stream(stream)), "inverseNTT_batch")
+
+
+def barrett(a, b, q, mu, qbit, stream=None):
+    """poly_arithmetic.cuh:9 -- a[i] = a[i]*b[i] mod q over a.numel() coefficients"""
+    m = Moduli([q], [mu], [qbit])
+    _check(lib().mi355ntt_barrett_raw(_ptr(a), _ptr(a), _ptr(b), int(a.numel()), 1, 1, *m.args(), _stream(stream)), "barrett")
+
+
+def barrett_batch(a, b, n, division, moduli, num=None, stream=None):
+    """poly_arithmetic.cuh:36"""
+    num = int(num if num is not None else a.numel() // n)
+    _check(lib().mi355ntt_barrett_raw(_ptr(a), _ptr(a), _ptr(b), int(n), num, int(division), *moduli.args(), _stream(stream)),
+           "barrett_batch")
+
+
+def barrett_batch_3param(c, a, b, n, division, moduli, num=None, stream=None):
+    """poly_arithmetic.cuh:68"""
+    num = int(num if num is not None else a.numel() // n)
+    _check(lib().mi355ntt_barrett_raw(_ptr(c), _ptr(a), _ptr(b), int(n), num, int(division), *moduli.args(), _stream(stream)),
+           "barrett_batch_3param")
+
+
+def barrett_int(a, b, q, mu, qbit, stream=None):
+    """poly_arithmetic.cuh:100"""
+    _check(lib().mi355ntt_barrett_int_raw(_ptr(a), int(b), int(a.numel()), int(q), int(mu), int(qbit), _stream(stream)),
+           "barrett_int")
+
+
+def half_poly_mul_device(device_a, device_b, n, stream, q, mu, bit_length_, psi_powers, psiinv_powers):
+    """poly_arithmetic.cuh:303-310: a = INTT(NTT(a) (.) b), b already in the NTT domain"""
+    forwardNTT(device_a, n, stream, q, mu, bit_length_, psi_powers)
+    barrett(device_a, device_b, q, mu, bit_length_, stream)
+    inverseNTT(device_a, n, stream, q, mu, bit_length_, psiinv_powers)
+
+
+def full_poly_mul_device(device_a, device_b, n, stream1, stream2, q, mu, bit_length_, psi_powers):
+    """poly_arithmetic.cuh:296-301: NTT both operands and multiply pointwise (result stays in the NTT domain)"""
+    import torch
+    forwardNTTdouble(device_a, device_b, n, stream1, stream2, q, mu, bit_length_, psi_powers)
+    s2 = stream2 if stream2 is not None else torch.cuda.current_stream()
+    if stream1 is not None and stream1 is not s2:
+        s2.wait_stream(stream1)   # the reference relies on legacy default-stream ordering here
+    barrett(device_a, device_b, q, mu, bit_length_, s2)
+
+
+def full_poly_mul(host_a, host_b, n, q, mu, bit_length_, psi_powers, psiinv_powers, device="cuda:0"):
+    """poly_arithmetic.cuh:277-294: H2D, NTT x2, pointwise, INTT, D2H; returns a new host array"""
+    import torch
+    da, db = to_device(host_a, device), to_device(host_b, device)
+    s = torch.cuda.current_stream()
+    full_poly_mul_device(da, db, n, s, s, q, mu, bit_length_, psi_powers)
+    inverseNTT(da, n, s, q, mu, bit_length_, psiinv_powers)
+    return to_host(da)

@@ -1,0 +1,117 @@
+"""CPU: the C-ABI library loads, exports every symbol include/mi355ntt.h declares, its host-only
+parameter helpers agree with the oracle, and argument errors are reported (no GPU compute here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import params as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mi355ntt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355ntt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(native):
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    raw = ctypes.CDLL(native.LIB_PATH)
+    missing = [s for s in syms if not hasattr(raw, s)]
+    assert not missing, missing
+    # and the Python binding covers the same set
+    assert sorted(native._SIGNATURES) == syms
+
+
+def test_library_is_the_in_tree_hip_build(native):
+    assert os.path.dirname(native.LIB_PATH) == os.path.join(ROOT, "ntt-cuda_amd")
+    assert b"gfx950" in native.lib().mi355ntt_version()
+
+
+def test_host_helpers_match_oracle(native, oracle):
+    L = oracle.lib()
+    moduli = [v[0] for v in P.REF_PARAMS.values()] + P.Q60 + P.Q55 + [v[0] for v in P.EDGE_PRIMES.values()] + [P.GAMMA61]
+    rng = np.random.default_rng(3)
+    for q in moduli:
+        k = native.bit_length(q)
+        assert k == L.orc_bit_length(q) == int(q).bit_length()       # demo.cu:69 formula agrees with the exact length
+        assert native.barrett_mu(q, k) == L.orc_mu(q, k)
+        for a in [2, 3, q - 1] + [int(x) % q for x in rng.integers(1, 1 << 62, 5, dtype=np.uint64)]:
+            e = int(rng.integers(0, 1 << 62))
+            assert native.modpow128(a, e, q) == pow(a, e, q) == L.orc_modpow(a, e, q)
+            assert native.lib().mi355ntt_mulmod(a, e, q) == (a * e) % q
+    for bits in (1, 5, 12, 15, 16):
+        for a in (0, 1, 5, (1 << bits) - 1):
+            assert native.bitReverse(a, bits) == L.orc_bitrev(a, bits)
+
+
+@pytest.mark.parametrize("n", sorted(P.REF_PARAMS))
+def test_get_params_and_tables(native, oracle, n):
+    q, psi, psiinv, ninv, qbit = P.REF_PARAMS[n]
+    assert native.getParams(n) == (q, psi, psiinv, ninv, qbit)
+    assert native.modinv128(psi, q) == psiinv and native.modinv128(n, q) == ninv
+    tp, ti = native.fillTablePsi128(psi, q, psiinv, n)
+    prm = oracle.Params(n, [q], [psi])
+    assert np.array_equal(tp, prm.psi_tabs[0]) and np.array_equal(ti, prm.psiinv_tabs[0])
+
+
+def test_tables_60bit_digest(native):
+    (n, q, psi), (d_tab, _, _) = [(k, v) for k, v in P.GOLDEN_DIGESTS.items() if k[1] == P.Q60[0]][0]
+    tp, _ = native.fillTablePsi128(psi, q, native.modinv128(psi, q), n)
+    assert P.digest(tp) == d_tab
+
+
+def test_argument_errors_are_reported(native):
+    L = native.lib()
+    h = ctypes.c_void_p()
+    q = (ctypes.c_ulonglong * 1)(P.Q60[0])
+    psi = (ctypes.c_ulonglong * 1)(P.PSI60[0])
+    # unsupported ring degree (the reference silently launches nothing, ntt_60bit.cuh:344-347)
+    assert L.mi355ntt_ctx_create(ctypes.byref(h), 1000, 1, q, psi, 0) == native.EUNSUPPORTED
+    assert L.mi355ntt_ctx_create(ctypes.byref(h), 1024, 1, q, psi, 0) == native.EUNSUPPORTED
+    assert L.mi355ntt_ctx_create(ctypes.byref(h), 32768, 17, q, psi, 0) == native.EUNSUPPORTED
+    assert L.mi355ntt_ctx_create(ctypes.byref(h), 32768, 0, q, psi, 0) == native.EUNSUPPORTED
+    assert L.mi355ntt_ctx_create(None, 32768, 1, q, psi, 0) == native.EINVAL
+    # psi that is not a primitive 2n-th root, even modulus, modulus too wide
+    bad = (ctypes.c_ulonglong * 1)(P.PSI60[0] + 1)
+    assert L.mi355ntt_ctx_create(ctypes.byref(h), 32768, 1, q, bad, 0) == native.EPARAM
+    even = (ctypes.c_ulonglong * 1)(P.Q60[0] + 1)
+    assert L.mi355ntt_ctx_create(ctypes.byref(h), 32768, 1, even, psi, 0) == native.EUNSUPPORTED
+    wide = (ctypes.c_ulonglong * 1)((1 << 63) + 1)
+    assert L.mi355ntt_ctx_create(ctypes.byref(h), 32768, 1, wide, psi, 0) == native.EUNSUPPORTED
+    assert h.value is None
+    # null handles / pointers
+    assert L.mi355ntt_forward_batch(None, None, 1, 1, None) == native.EINVAL
+    assert L.mi355ntt_forward_raw(None, 4096, None, P.Q60[0], 1, 60, None) == native.EINVAL
+    assert L.mi355ntt_ctx_destroy(None) == native.OK
+    assert native.lib().mi355ntt_strerror(native.EPARAM).startswith(b"inconsistent")
+
+
+def test_no_gpu_means_loud_failure_not_fallback(native):
+    """The product path has no CPU fallback: without a device the context constructor raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.NTTError) as e:
+        native.NTTContext(32768, P.Q60[:1], P.PSI60[:1])
+    assert e.value.code == native.EHIP
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under ntt-cuda_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("ntt-cuda_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dirpath:
+                continue
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".hip", ".cuh", ".h", "Makefile")):
+                    t = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"oracle_py|liboracle|ntt_oracle|orc_", t):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
