@@ -33,9 +33,10 @@ struct FastTables {
     ModSet mods;
     // [P][n] pairs {w, floor(w*2^64/q)}: twiddle and its Shoup companion, interleaved so one 16-byte
     // load fetches both.  Same indexing as the reference tables (entry length+p for stage `length`).
-    u64* d_fwd = nullptr;   // psi^bitrev(i)
-    u64* d_inv = nullptr;   // psi^-bitrev(i); entry 1 additionally carries the n^-1 scaling (see kernels_fast.hip)
-    u64* d_ninv = nullptr;  // [P] pairs {n^-1, shoup(n^-1)}
+    u64* d_fwd = nullptr;      // psi^bitrev(i)
+    u64* d_inv = nullptr;      // psi^-bitrev(i)
+    void* d_primes = nullptr;  // [P] PrimeDev records (ntt_core.cuh)
+    int hl = 6;                // headroom class of the context: min over primes of (64 - bit length), capped at 6
     const u64* d_psi = nullptr;     // reference-format tables owned by the context (fallback path)
     const u64* d_psiinv = nullptr;
 };

@@ -1,42 +1,167 @@
 // kernels_fast.hip -- throughput path of the NTT engine (context entry points).
+//
+// forward / inverse / fused polymul: one workgroup per polynomial, single pass over HBM, see ntt_core.cuh.
+// Replaces CTBasedNTTInner*/GSBasedINTTInner* (ntt_60bit.cuh:63-265,388-606) and the
+// forwardNTT_batch -> barrett_batch -> inverseNTT_batch triple of the BFV drivers
+// (bfv_encryption.cuh:268-271, bfv_keygen.cuh:129-133, bfv_decryption.cuh:98-101).
 #include "kernels.hpp"
 #include "modarith.cuh"
+#include "ntt_core.cuh"
 
 #include <cstring>
 #include <vector>
 
 namespace mi355ntt {
 
-hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
-                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv)
+namespace {
+
+template <int LOGN>
+__device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restrict__ poly, unsigned t)
 {
-    t->n = n;
-    t->log_n = 0;
-    while ((1u << t->log_n) < n) t->log_n++;
-    t->num_primes = num_primes;
-    std::memset(&t->mods, 0, sizeof(t->mods));
-    for (unsigned i = 0; i < num_primes; i++) {
-        t->prime[i] = prime[i];
-        t->mods.q[i] = prime[i].q;
-        t->mods.mu[i] = prime[i].mu;
-        t->mods.k[i] = prime[i].k;
+#pragma unroll
+    for (int r = 0; r < 32; r++) v[r] = poly[((unsigned)r << Geo<LOGN>::B0) | t];
+}
+
+template <int LOGN>
+__device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restrict__ poly, unsigned t)
+{
+#pragma unroll
+    for (int r = 0; r < 32; r++) poly[((unsigned)r << Geo<LOGN>::B0) | t] = v[r];
+}
+
+// ---- forward: natural -> bit-reversed, canonical ------------------------------------------------
+template <int LOGN, int HL>
+__global__ void __launch_bounds__(Geo<LOGN>::T, 4)
+k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+          unsigned prime_base)
+{
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    const unsigned y = blockIdx.x;
+    const unsigned idx = prime_base + y % division;
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * G::N;
+    u64* poly = a + (size_t)y * G::N;
+    const unsigned t = threadIdx.x;
+    u64 v[32];
+    load_coalesced<LOGN>(v, poly, t);
+    forward_core<LOGN, HL>(v, twp, t, p, lds);
+#pragma unroll
+    for (int r = 0; r < 32; r++) v[r] = canon_2q(reduce_2q(v[r], p), p.q);
+    exchange<LOGN, 0, G::B0>(v, lds, t);
+    store_coalesced<LOGN>(v, poly, t);
+}
+
+// ---- inverse: bit-reversed -> natural, scaled by n^-1, canonical --------------------------------
+template <int LOGN, int HL>
+__global__ void __launch_bounds__(Geo<LOGN>::T, 4)
+k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+          unsigned prime_base)
+{
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    const unsigned y = blockIdx.x;
+    const unsigned idx = prime_base + y % division;
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * G::N;
+    u64* poly = a + (size_t)y * G::N;
+    const unsigned t = threadIdx.x;
+    u64 v[32];
+    load_coalesced<LOGN>(v, poly, t);
+    exchange<LOGN, G::B0, 0>(v, lds, t);
+    inverse_core<LOGN, HL>(v, twp, t, p, lds);
+#pragma unroll
+    for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL>(v[r], p);
+    store_coalesced<LOGN>(v, poly, t);
+}
+
+// ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
+template <int LOGN, int HL>
+__global__ void __launch_bounds__(Geo<LOGN>::T, 4)
+k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
+          const PrimeDev* __restrict__ primes, unsigned division)
+{
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    const unsigned y = blockIdx.x;
+    const unsigned idx = y % division;
+    const PrimeDev p = primes[idx];
+    u64* poly = a + (size_t)y * G::N;
+    const u64* bp = bhat + (size_t)y * G::N;
+    const unsigned t = threadIdx.x;
+    u64 v[32];
+    load_coalesced<LOGN>(v, poly, t);
+    forward_core<LOGN, HL>(v, twf + (size_t)idx * G::N, t, p, lds);
+    // layout 0: this thread holds NTT values 32t .. 32t+31; the inverse starts from the same layout
+    const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(bp + ((size_t)t << 5));
+#pragma unroll
+    for (int r = 0; r < 32; r += 2) {
+        const ulonglong2 bb = b2[r >> 1];
+        const u64 x0 = canon_2q(reduce_2q(v[r], p), p.q);
+        const u64 x1 = canon_2q(reduce_2q(v[r + 1], p), p.q);
+        v[r] = barrett_mul(x0, bb.x, p.q, p.mu, p.k);          // poly_arithmetic.cuh:36-66, Algorithm 7
+        v[r + 1] = barrett_mul(x1, bb.y, p.q, p.mu, p.k);
     }
-    t->d_psi = d_psi;
-    t->d_psiinv = d_psiinv;
-    (void)h_psi;
-    (void)h_psiinv;
-    return hipSuccess;
+    inverse_core<LOGN, HL>(v, twi + (size_t)idx * G::N, t, p, lds);
+#pragma unroll
+    for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL>(v[r], p);
+    store_coalesced<LOGN>(v, poly, t);
 }
 
-void fast_tables_destroy(FastTables* t)
+// ---- pointwise c = a (.) b, 16 bytes per lane ----------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_pointwise(u64* __restrict__ c, const u64* __restrict__ a, const u64* __restrict__ b, unsigned n, unsigned division,
+            const PrimeDev* __restrict__ primes)
 {
-    if (t->d_fwd) (void)hipFree(t->d_fwd);
-    if (t->d_inv) (void)hipFree(t->d_inv);
-    if (t->d_ninv) (void)hipFree(t->d_ninv);
-    t->d_fwd = t->d_inv = t->d_ninv = nullptr;
+    const unsigned y = blockIdx.y;
+    const PrimeDev p = primes[y % division];
+    const size_t base = (size_t)y * n;
+    const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a + base);
+    const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b + base);
+    ulonglong2* c2 = reinterpret_cast<ulonglong2*>(c + base);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n / 2; i += gridDim.x * 256) {
+        const ulonglong2 x = a2[i], w = b2[i];
+        ulonglong2 r;
+        r.x = barrett_mul(x.x, w.x, p.q, p.mu, p.k);
+        r.y = barrett_mul(x.y, w.y, p.q, p.mu, p.k);
+        c2[i] = r;
+    }
 }
 
-static ModSet shifted(const ModSet& m, unsigned base, unsigned division)
+template <int LOGN>
+hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
+                      hipStream_t s)
+{
+    dim3 g(num), b(Geo<LOGN>::T);
+    if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    return hipGetLastError();
+}
+
+template <int LOGN>
+hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
+                      hipStream_t s)
+{
+    dim3 g(num), b(Geo<LOGN>::T);
+    if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    return hipGetLastError();
+}
+
+template <int LOGN>
+hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr, unsigned num,
+                      unsigned division, hipStream_t s)
+{
+    dim3 g(num), b(Geo<LOGN>::T);
+    if (hl >= 6) k_polymul<LOGN, 6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+    else if (hl >= 4) k_polymul<LOGN, 4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+    else k_polymul<LOGN, 2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+    return hipGetLastError();
+}
+
+ModSet shifted(const ModSet& m, unsigned base, unsigned division)
 {
     ModSet r;
     std::memset(&r, 0, sizeof(r));
@@ -48,24 +173,128 @@ static ModSet shifted(const ModSet& m, unsigned base, unsigned division)
     return r;
 }
 
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
+                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv)
+{
+    t->n = n;
+    t->log_n = 0;
+    while ((1u << t->log_n) < n) t->log_n++;
+    t->num_primes = num_primes;
+    std::memset(&t->mods, 0, sizeof(t->mods));
+    t->d_psi = d_psi;
+    t->d_psiinv = d_psiinv;
+    t->hl = 6;
+    std::vector<PrimeDev> pd(num_primes);
+    for (unsigned i = 0; i < num_primes; i++) {
+        const PrimeParams& pp = prime[i];
+        t->prime[i] = pp;
+        t->mods.q[i] = pp.q;
+        t->mods.mu[i] = pp.mu;
+        t->mods.k[i] = pp.k;
+        int hl = 64 - (int)pp.k;
+        if (hl < t->hl) t->hl = hl;
+        PrimeDev& d = pd[i];
+        d.q = pp.q;
+        d.nq = 0ULL - pp.q;
+        d.ninv = pp.ninv;
+        d.ninv_p = shoup(pp.ninv, pp.q);
+        const u64 w1 = h_psiinv[(size_t)i * n + 1];           // psi^-bitrev(1): the single twiddle of the last GS stage
+        d.w1n = mulmod(w1, pp.ninv, pp.q);
+        d.w1n_p = shoup(d.w1n, pp.q);
+        d.mu = pp.mu;
+        d.k = pp.k;
+        const unsigned g = pp.k - 1 < 16 ? pp.k - 1 : 16;
+        d.red_sh1 = pp.k - 1 - g;
+        d.red_sh2 = g;
+        d.red_c = (u32)((((u128)1) << (31 + pp.k)) / pp.q);
+    }
+    const size_t words = (size_t)num_primes * n;
+    std::vector<TwPair> hf(words), hi(words);
+    for (unsigned i = 0; i < num_primes; i++)
+        for (unsigned j = 0; j < n; j++) {
+            const size_t o = (size_t)i * n + j;
+            hf[o].w = h_psi[o];
+            hf[o].wp = shoup(h_psi[o], prime[i].q);
+            hi[o].w = h_psiinv[o];
+            hi[o].wp = shoup(h_psiinv[o], prime[i].q);
+        }
+    hipError_t e;
+    if ((e = hipMalloc((void**)&t->d_fwd, words * sizeof(TwPair))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&t->d_inv, words * sizeof(TwPair))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&t->d_primes, num_primes * sizeof(PrimeDev))) != hipSuccess) return e;
+    if ((e = hipMemcpy(t->d_fwd, hf.data(), words * sizeof(TwPair), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(t->d_inv, hi.data(), words * sizeof(TwPair), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(t->d_primes, pd.data(), num_primes * sizeof(PrimeDev), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+void fast_tables_destroy(FastTables* t)
+{
+    if (t->d_fwd) (void)hipFree(t->d_fwd);
+    if (t->d_inv) (void)hipFree(t->d_inv);
+    if (t->d_primes) (void)hipFree(t->d_primes);
+    t->d_fwd = t->d_inv = nullptr;
+    t->d_primes = nullptr;
+}
+
 hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
-    return compat_forward_batch(d_a, t.n, t.d_psi + (size_t)prime_base * t.n, num, division, shifted(t.mods, prime_base, division), s);
+    const TwPair* tw = reinterpret_cast<const TwPair*>(t.d_fwd);
+    const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
+    switch (t.log_n) {
+    case 11: return launch_fwd<11>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 12: return launch_fwd<12>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 13: return launch_fwd<13>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 14: return launch_fwd<14>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 15: return launch_fwd<15>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    default:
+        return compat_forward_batch(d_a, t.n, t.d_psi + (size_t)prime_base * t.n, num, division,
+                                    shifted(t.mods, prime_base, division), s);
+    }
 }
 
 hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
-    return compat_inverse_batch(d_a, t.n, t.d_psiinv + (size_t)prime_base * t.n, num, division, shifted(t.mods, prime_base, division), s);
+    const TwPair* tw = reinterpret_cast<const TwPair*>(t.d_inv);
+    const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
+    switch (t.log_n) {
+    case 11: return launch_inv<11>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 12: return launch_inv<12>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 13: return launch_inv<13>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 14: return launch_inv<14>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 15: return launch_inv<15>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    default:
+        return compat_inverse_batch(d_a, t.n, t.d_psiinv + (size_t)prime_base * t.n, num, division,
+                                    shifted(t.mods, prime_base, division), s);
+    }
 }
 
 hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u64* d_b, unsigned num, unsigned division,
                           hipStream_t s)
 {
-    return compat_pointwise(d_c, d_a, d_b, t.n, num, division, t.mods, s);
+    unsigned gx = (t.n / 2 + 255) / 256;
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, num);
+    k_pointwise<<<grid, 256, 0, s>>>(d_c, d_a, d_b, t.n, division, reinterpret_cast<const PrimeDev*>(t.d_primes));
+    return hipGetLastError();
 }
 
 hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s)
 {
+    const TwPair* twf = reinterpret_cast<const TwPair*>(t.d_fwd);
+    const TwPair* twi = reinterpret_cast<const TwPair*>(t.d_inv);
+    const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
+    switch (t.log_n) {
+    case 11: return launch_mul<11>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 12: return launch_mul<12>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 13: return launch_mul<13>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 14: return launch_mul<14>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 15: return launch_mul<15>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    default: break;
+    }
     hipError_t e = fast_forward_batch(t, d_a, num, division, 0, s);
     if (e != hipSuccess) return e;
     e = fast_pointwise(t, d_a, d_a, d_bhat, num, division, s);
