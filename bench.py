@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- forward+inverse 60-bit NTT throughput at n = 2^15 on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: forward_batch then inverse_batch over `--batch`
+polynomials per GPU (default 1024 = BASELINE configs[3]'s per-GPU shard: n=32768, 4 x 60-bit RNS primes;
+256 MiB per GPU, i.e. past the Infinity Cache).  Inputs are synthetic uniform residues already resident
+in HBM when the timed region starts.  Polynomials are independent, so ranks shard the batch with no
+data-path collective (weak scaling); the only collectives are the barrier and the max-over-ranks of the
+elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "ntt-cuda_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+# BASELINE configs 2-4: the four largest 60-bit primes = 1 mod 2^16, minimal 2n-th roots
+Q60 = [1152921504606584833, 1152921504598720513, 1152921504597016577, 1152921504595968001]
+PSI60 = [4443670208963, 100545759574150, 31693996050849, 88651361085495]
+HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
+BYTES_PER_TRANSFORM = 2 * 32768 * 8   # one in-place transform reads and writes the polynomial once
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="polynomials per GPU")
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args()
+
+
+def synth(torch, num, n, qs, device, seed):
+    """uniform residues: 60-bit randoms, one conditional subtraction (all q are within 2^-36 of 2^60)"""
+    g = torch.Generator(device=device).manual_seed(seed)
+    a = torch.randint(0, 1 << 60, (num, n), dtype=torch.int64, device=device, generator=g)
+    qcol = torch.tensor(qs, dtype=torch.int64, device=device)[torch.arange(num, device=device) % len(qs)].unsqueeze(1)
+    return torch.where(a >= qcol, a - qcol, a).contiguous()
+
+
+def cpu_baseline(n, qs, psis):
+    """The oracle (literal restatement of the reference's Barrett CT/GS kernels; the reference ships no CPU NTT)
+    timed on this host's cores over a bounded sample of the same workload."""
+    import numpy as np
+    import oracle_py as oracle
+    cores = os.cpu_count() or 1
+    so = None
+    try:        # host-tuned build of the same source for the timing (the in-tree .so is portable x86-64)
+        tmp = tempfile.mkdtemp(prefix="orc_native_")
+        so = os.path.join(tmp, "liboracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=gnu11", "-o", so,
+                               os.path.join(ROOT, "oracle", "ntt_oracle.c"), "-lm"], stderr=subprocess.DEVNULL)
+        import ctypes
+        lib = ctypes.CDLL(so)
+    except Exception:
+        lib = oracle.lib()
+    prm = oracle.Params(n, qs, psis)
+    num = 64 * max(1, cores // 8)
+    num = max(num, 2 * cores)
+    num -= num % len(qs)
+    a = oracle.synth_batch(n, num, qs, 1)
+    u64p, u32p = oracle.u64p, oracle.u32p
+    import ctypes
+
+    def call(name, arr, tabs):
+        f = getattr(lib, name)
+        f.restype = None
+        f.argtypes = [u64p, ctypes.c_uint, u64p, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, ctypes.c_int]
+        f(arr.ctypes.data_as(u64p), n, tabs.ctypes.data_as(u64p), num, len(qs), prm.q.ctypes.data_as(u64p),
+          prm.mu.ctypes.data_as(u64p), prm.k.ctypes.data_as(u32p), cores)
+
+    work = a.copy()
+    call("orc_forward_batch", work, prm.psi_tabs)        # warm-up + correctness of the round trip
+    call("orc_inverse_batch", work, prm.psiinv_tabs)
+    assert np.array_equal(work, a)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        call("orc_forward_batch", work, prm.psi_tabs)
+        call("orc_inverse_batch", work, prm.psiinv_tabs)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el * cores >= 12.0 or el > 20.0:
+            break
+    return {"value": num * reps / el, "unit": "fwd+inv NTT pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d polys (n=%d, %d primes) x %d passes, OpenMP over polynomials, %.1f s wall" % (num, n, len(qs), reps, el)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import ntt_cuda_amd as ntt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n, P, batch = args.n, len(Q60), args.batch
+    ctx = ntt.NTTContext(n, Q60, PSI60, device=local)
+    # this rank's shard of the global batch: whole polynomials, shard size a multiple of the prime count so
+    # polynomial y keeps prime y % P; inputs resident in HBM before timing starts
+    a = synth(torch, batch, n, Q60, dev, seed=1000 + rank)
+    a0 = a.clone()
+
+    def step():
+        ctx.forward_batch(a, batch)
+        ctx.inverse_batch(a, batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    assert torch.equal(a, a0), "round trip broke the data"
+
+    # per-kernel durations, measured live with HIP events on the launch stream (torch's current stream)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        ctx.forward_batch(a, batch)
+        ev[k][1].record()
+        ctx.inverse_batch(a, batch)
+        ev[k][2].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    inv_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    assert torch.equal(a, a0)
+
+    pairs_per_s = world * batch * args.steps / elapsed
+    dom_name, dom_ms = ("k_forward", fwd_ms) if fwd_ms >= inv_ms else ("k_inverse", inv_ms)
+    alg_bytes = batch * BYTES_PER_TRANSFORM                       # per launch of either kernel
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9                  # GB/s
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "forward+inverse NTT/s (n=2^15, 60-bit q) per GPU; % HBM roofline",
+        "value": pairs_per_s,
+        "unit": "fwd+inv NTT pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": "n=32768, 4x60-bit RNS primes, %d polys/GPU (configs[3] per-GPU shard), forward_batch+inverse_batch, "
+                               "inputs resident in HBM" % batch,
+                   "n": n, "primes": P, "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": "shard%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "kernel": dom_name,
+                     "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "pair_frac_of_hbm_peak": pairs_per_s / world * 2 * BYTES_PER_TRANSFORM / HBM_PEAK},
+        "kernel_ms": {"k_forward": fwd_ms, "k_inverse": inv_ms},
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        # BASELINE configs[2]: batch 256, pointwise modmul fused (NTT -> (.) -> INTT in one kernel), and configs[1]: batch 1
+        b256 = synth(torch, 256, n, Q60, dev, seed=7)
+        bh = synth(torch, 256, n, Q60, dev, seed=8)
+        ctx.forward_batch(bh, 256)
+        for _ in range(3):
+            ctx.polymul_batch(b256, bh, 256)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ctx.polymul_batch(b256, bh, 256)
+        e1.record()
+        torch.cuda.synchronize()
+        mul_ms = e0.elapsed_time(e1) / 20
+        one = synth(torch, 1, n, Q60[:1], dev, seed=9)
+        for _ in range(3):
+            ctx.forward(one, 0)
+            ctx.inverse(one, 0)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(200):
+            ctx.forward(one, 0)
+            ctx.inverse(one, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        out["extras"] = {"config2_fused_polymul_batch256_per_s": 256 / (mul_ms * 1e-3), "config2_fused_polymul_ms": mul_ms,
+                         "config1_batch1_fwd_inv_pair_us": e0.elapsed_time(e1) / 200 * 1e3}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, Q60, PSI60)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@
 #include "kernels.hpp"
 #include "modarith.cuh"
 #include "ntt_core.cuh"
+#include "kernels_fast_impl.cuh"
 
 #include <cstring>
 #include <vector>
@@ -14,99 +15,6 @@
 namespace mi355ntt {
 
 namespace {
-
-template <int LOGN>
-__device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restrict__ poly, unsigned t)
-{
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = poly[((unsigned)r << Geo<LOGN>::B0) | t];
-}
-
-template <int LOGN>
-__device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restrict__ poly, unsigned t)
-{
-#pragma unroll
-    for (int r = 0; r < 32; r++) poly[((unsigned)r << Geo<LOGN>::B0) | t] = v[r];
-}
-
-// ---- forward: natural -> bit-reversed, canonical ------------------------------------------------
-template <int LOGN, int HL>
-__global__ void __launch_bounds__(Geo<LOGN>::T, 4)
-k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-          unsigned prime_base)
-{
-    using G = Geo<LOGN>;
-    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned y = blockIdx.x;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    u64* poly = a + (size_t)y * G::N;
-    const unsigned t = threadIdx.x;
-    u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
-    forward_core<LOGN, HL>(v, twp, t, p, lds);
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = canon_2q(reduce_2q(v[r], p), p.q);
-    exchange<LOGN, 0, G::B0>(v, lds, t);
-    store_coalesced<LOGN>(v, poly, t);
-}
-
-// ---- inverse: bit-reversed -> natural, scaled by n^-1, canonical --------------------------------
-template <int LOGN, int HL>
-__global__ void __launch_bounds__(Geo<LOGN>::T, 4)
-k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-          unsigned prime_base)
-{
-    using G = Geo<LOGN>;
-    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned y = blockIdx.x;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    u64* poly = a + (size_t)y * G::N;
-    const unsigned t = threadIdx.x;
-    u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
-    exchange<LOGN, G::B0, 0>(v, lds, t);
-    inverse_core<LOGN, HL>(v, twp, t, p, lds);
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL>(v[r], p);
-    store_coalesced<LOGN>(v, poly, t);
-}
-
-// ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
-template <int LOGN, int HL>
-__global__ void __launch_bounds__(Geo<LOGN>::T, 4)
-k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
-          const PrimeDev* __restrict__ primes, unsigned division)
-{
-    using G = Geo<LOGN>;
-    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned y = blockIdx.x;
-    const unsigned idx = y % division;
-    const PrimeDev p = primes[idx];
-    u64* poly = a + (size_t)y * G::N;
-    const u64* bp = bhat + (size_t)y * G::N;
-    const unsigned t = threadIdx.x;
-    u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
-    forward_core<LOGN, HL>(v, twf + (size_t)idx * G::N, t, p, lds);
-    // layout 0: this thread holds NTT values 32t .. 32t+31; the inverse starts from the same layout
-    const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(bp + ((size_t)t << 5));
-#pragma unroll
-    for (int r = 0; r < 32; r += 2) {
-        const ulonglong2 bb = b2[r >> 1];
-        const u64 x0 = canon_2q(reduce_2q(v[r], p), p.q);
-        const u64 x1 = canon_2q(reduce_2q(v[r + 1], p), p.q);
-        v[r] = barrett_mul(x0, bb.x, p.q, p.mu, p.k);          // poly_arithmetic.cuh:36-66, Algorithm 7
-        v[r + 1] = barrett_mul(x1, bb.y, p.q, p.mu, p.k);
-    }
-    inverse_core<LOGN, HL>(v, twi + (size_t)idx * G::N, t, p, lds);
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL>(v[r], p);
-    store_coalesced<LOGN>(v, poly, t);
-}
 
 // ---- pointwise c = a (.) b, 16 bytes per lane ----------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -126,39 +34,6 @@ k_pointwise(u64* __restrict__ c, const u64* __restrict__ a, const u64* __restric
         r.y = barrett_mul(x.y, w.y, p.q, p.mu, p.k);
         c2[i] = r;
     }
-}
-
-template <int LOGN>
-hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
-                      hipStream_t s)
-{
-    dim3 g(num), b(Geo<LOGN>::T);
-    if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    return hipGetLastError();
-}
-
-template <int LOGN>
-hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
-                      hipStream_t s)
-{
-    dim3 g(num), b(Geo<LOGN>::T);
-    if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    return hipGetLastError();
-}
-
-template <int LOGN>
-hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr, unsigned num,
-                      unsigned division, hipStream_t s)
-{
-    dim3 g(num), b(Geo<LOGN>::T);
-    if (hl >= 6) k_polymul<LOGN, 6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-    else if (hl >= 4) k_polymul<LOGN, 4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-    else k_polymul<LOGN, 2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-    return hipGetLastError();
 }
 
 ModSet shifted(const ModSet& m, unsigned base, unsigned division)
@@ -245,11 +120,11 @@ hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsig
     const TwPair* tw = reinterpret_cast<const TwPair*>(t.d_fwd);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
     switch (t.log_n) {
-    case 11: return launch_fwd<11>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 12: return launch_fwd<12>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 13: return launch_fwd<13>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 14: return launch_fwd<14>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 15: return launch_fwd<15>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 11: return fast_fwd_11(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 12: return fast_fwd_12(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 13: return fast_fwd_13(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 14: return fast_fwd_14(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 15: return fast_fwd_15(t.hl, d_a, tw, pr, num, division, prime_base, s);
     default:
         return compat_forward_batch(d_a, t.n, t.d_psi + (size_t)prime_base * t.n, num, division,
                                     shifted(t.mods, prime_base, division), s);
@@ -261,11 +136,11 @@ hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsig
     const TwPair* tw = reinterpret_cast<const TwPair*>(t.d_inv);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
     switch (t.log_n) {
-    case 11: return launch_inv<11>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 12: return launch_inv<12>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 13: return launch_inv<13>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 14: return launch_inv<14>(t.hl, d_a, tw, pr, num, division, prime_base, s);
-    case 15: return launch_inv<15>(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 11: return fast_inv_11(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 12: return fast_inv_12(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 13: return fast_inv_13(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 14: return fast_inv_14(t.hl, d_a, tw, pr, num, division, prime_base, s);
+    case 15: return fast_inv_15(t.hl, d_a, tw, pr, num, division, prime_base, s);
     default:
         return compat_inverse_batch(d_a, t.n, t.d_psiinv + (size_t)prime_base * t.n, num, division,
                                     shifted(t.mods, prime_base, division), s);
@@ -288,11 +163,11 @@ hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, 
     const TwPair* twi = reinterpret_cast<const TwPair*>(t.d_inv);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
     switch (t.log_n) {
-    case 11: return launch_mul<11>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
-    case 12: return launch_mul<12>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
-    case 13: return launch_mul<13>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
-    case 14: return launch_mul<14>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
-    case 15: return launch_mul<15>(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 11: return fast_mul_11(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 12: return fast_mul_12(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 13: return fast_mul_13(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 14: return fast_mul_14(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
+    case 15: return fast_mul_15(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
     default: break;
     }
     hipError_t e = fast_forward_batch(t, d_a, num, division, 0, s);

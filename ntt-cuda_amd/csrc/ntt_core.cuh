@@ -34,6 +34,37 @@ struct TwPair {       // {w, floor(w * 2^64 / q)}
     u64 w, wp;
 };
 
+// Buffer-descriptor loads/stores: one 32-bit lane offset VGPR serves every access of a thread, the
+// per-register displacement rides in the scalar offset / immediate (no 64-bit address arithmetic in VGPRs).
+typedef u32 v2u32 __attribute__((ext_vector_type(2)));
+typedef u32 v4u32 __attribute__((ext_vector_type(4)));
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, u32 bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u64 buf_load_u64(BufRsrc r, u32 voff, u32 soff)
+{
+    const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return (u64)x.x | ((u64)x.y << 32);
+}
+__device__ __forceinline__ void buf_store_u64(BufRsrc r, u32 voff, u32 soff, u64 v)
+{
+    v2u32 x;
+    x.x = lo32(v);
+    x.y = hi32(v);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+}
+__device__ __forceinline__ TwPair buf_load_tw(BufRsrc r, u32 voff, u32 soff)
+{
+    const v4u32 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    TwPair t;
+    t.w = (u64)x.x | ((u64)x.y << 32);
+    t.wp = (u64)x.z | ((u64)x.w << 32);
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------
 // lazy modular primitives
 // ------------------------------------------------------------------------------------------------
@@ -144,11 +175,48 @@ __device__ __forceinline__ unsigned elem_index(unsigned t, unsigned r)
     return ((t >> B) << (B + 5)) | (r << B) | (t & ((1u << B) - 1u));
 }
 
-template <int LOGN>
-__device__ __forceinline__ unsigned lds_slot(unsigned i)
+// LDS image: element i lives at row (i' >> 5), column (i' & 31) of a [ROWS][34] array of u64 (two words of
+// padding per row keep 8- and 16-byte accesses conflict-free for every layout), where i' = i without the
+// phase bit.  For a layout with register field at bit B the slot splits into a per-thread base and a
+// per-register COMPILE-TIME offset, so every access is base VGPR + immediate.
+template <int LOGN, int B>
+__device__ __forceinline__ unsigned slot_base(unsigned t)
 {
-    if constexpr (Geo<LOGN>::TWO_PHASE) i &= (1u << Geo<LOGN>::PB) - 1u;
-    return (i >> 5) * 34u + (i & 31u);
+    using G = Geo<LOGN>;
+    unsigned thi = t >> B, tlo = t & ((1u << B) - 1u);
+    if constexpr (B >= 5) {
+        unsigned i = (thi << (B + 5)) | tlo;                      // register field zero
+        if constexpr (G::TWO_PHASE) i &= (1u << G::PB) - 1u;
+        return (i >> 5) * 34u + (i & 31u);
+    } else {
+        unsigned row = thi << B;                                  // + (r >> (5-B)) from the register
+        if constexpr (G::TWO_PHASE) row &= (1u << (G::PB - 5)) - 1u;
+        return row * 34u + tlo;
+    }
+}
+
+template <int LOGN, int B>
+constexpr unsigned slot_off(unsigned r)
+{
+    using G = Geo<LOGN>;
+    if (B >= 5) {
+        unsigned c = r << B;
+        if (G::TWO_PHASE) c &= (1u << G::PB) - 1u;
+        return (c >> 5) * 34u;
+    }
+    return (r >> (5 - B)) * 34u + ((r & ((1u << (5 - B)) - 1u)) << B);
+}
+
+// which phase a (thread, register) element belongs to: the top index bit
+template <int LOGN, int B>
+__device__ __forceinline__ unsigned phase_of_thread(unsigned t)
+{
+    return (elem_index<B>(t, 0) >> Geo<LOGN>::PB) & 1u;
+}
+template <int LOGN, int B>
+constexpr unsigned phase_of_reg(unsigned r)
+{
+    return ((r << B) >> Geo<LOGN>::PB) & 1u;
 }
 
 // Transposition through LDS: registers hold layout BO on entry, layout BN on exit.
@@ -159,45 +227,36 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
     constexpr int PH = G::TWO_PHASE ? 2 : 1;
     constexpr bool W_REG_SPLIT = G::TWO_PHASE && (G::PB >= BO && G::PB < BO + 5);   // phase bit is a writer register bit
     constexpr bool R_REG_SPLIT = G::TWO_PHASE && (G::PB >= BN && G::PB < BN + 5);   // phase bit is a reader register bit
-    // thread-level phase membership when the phase bit lives in the thread id
-    const unsigned w_phase = G::TWO_PHASE ? ((elem_index<BO>(t, 0) >> G::PB) & 1u) : 0u;
-    const unsigned r_phase = G::TWO_PHASE ? ((elem_index<BN>(t, 0) >> G::PB) & 1u) : 0u;
+    const unsigned w_phase = G::TWO_PHASE ? phase_of_thread<LOGN, BO>(t) : 0u;
+    const unsigned r_phase = G::TWO_PHASE ? phase_of_thread<LOGN, BN>(t) : 0u;
+    u64* wbase = lds + slot_base<LOGN, BO>(t);
+    const u64* rbase = lds + slot_base<LOGN, BN>(t);
     u64 nv[32];
 #pragma unroll
     for (int ph = 0; ph < PH; ph++) {
         // ---- write ----
         if (W_REG_SPLIT || !G::TWO_PHASE || w_phase == (unsigned)ph) {
-            if constexpr (BO == 0) {
 #pragma unroll
-                for (int r = 0; r < 32; r += 2) {
-                    if (W_REG_SPLIT && (((unsigned)r << BO) >> G::PB & 1u) != (unsigned)ph) continue;
-                    ulonglong2 pr = make_ulonglong2(v[r], v[r + 1]);
-                    *reinterpret_cast<ulonglong2*>(&lds[lds_slot<LOGN>(elem_index<BO>(t, r))]) = pr;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 32; r++) {
-                    if (W_REG_SPLIT && ((((unsigned)r << BO) >> G::PB) & 1u) != (unsigned)ph) continue;
-                    lds[lds_slot<LOGN>(elem_index<BO>(t, r))] = v[r];
-                }
+            for (int r = 0; r < 32; r += (BO == 0 ? 2 : 1)) {
+                if (W_REG_SPLIT && phase_of_reg<LOGN, BO>(r) != (unsigned)ph) continue;
+                if constexpr (BO == 0)
+                    *reinterpret_cast<ulonglong2*>(wbase + slot_off<LOGN, BO>(r)) = make_ulonglong2(v[r], v[r + 1]);
+                else
+                    wbase[slot_off<LOGN, BO>(r)] = v[r];
             }
         }
         __syncthreads();
         // ---- read ----
         if (R_REG_SPLIT || !G::TWO_PHASE || r_phase == (unsigned)ph) {
-            if constexpr (BN == 0) {
 #pragma unroll
-                for (int r = 0; r < 32; r += 2) {
-                    if (R_REG_SPLIT && ((((unsigned)r << BN) >> G::PB) & 1u) != (unsigned)ph) continue;
-                    ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(&lds[lds_slot<LOGN>(elem_index<BN>(t, r))]);
+            for (int r = 0; r < 32; r += (BN == 0 ? 2 : 1)) {
+                if (R_REG_SPLIT && phase_of_reg<LOGN, BN>(r) != (unsigned)ph) continue;
+                if constexpr (BN == 0) {
+                    const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(rbase + slot_off<LOGN, BN>(r));
                     nv[r] = pr.x;
                     nv[r + 1] = pr.y;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 32; r++) {
-                    if (R_REG_SPLIT && ((((unsigned)r << BN) >> G::PB) & 1u) != (unsigned)ph) continue;
-                    nv[r] = lds[lds_slot<LOGN>(elem_index<BN>(t, r))];
+                } else {
+                    nv[r] = rbase[slot_off<LOGN, BN>(r)];
                 }
             }
         }
@@ -210,15 +269,24 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
 // ------------------------------------------------------------------------------------------------
 // in-register rounds
 // ------------------------------------------------------------------------------------------------
+// The whole transform is straight-line code; without fences the scheduler hoists dozens of twiddle loads
+// (4 VGPRs each) and spills.  A scheduling fence every SCHED_GROUP butterflies bounds the live set; the
+// other three waves of the SIMD cover the load latency.
+#ifndef MI355NTT_SCHED_GROUP
+#define MI355NTT_SCHED_GROUP 4
+#endif
+constexpr int SCHED_GROUP = MI355NTT_SCHED_GROUP;
+
 // Forward (CT) stages on register bits JHI..0 of a layout with register field at bit B.
 // S0 = global stage number of the first stage in this round.
 template <int LOGN, int HL, int B, int JHI>
-__device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, unsigned t, const PrimeDev& p)
+__device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
     constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
     constexpr bool EX = Lazy<HL>::EXACT;
     const u64 cq = (u64)Lazy<HL>::TQ * p.q;
     const unsigned thi = t >> B;
+    int cnt = 0;
 #pragma unroll
     for (int j = JHI; j >= 0; j--) {
         const int s = LOGN - 1 - (B + j);
@@ -227,24 +295,29 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
         for (int r0 = 0; r0 < 32; r0++) {
             if (r0 & (1 << j)) continue;
             const int r1 = r0 | (1 << j);
-            const unsigned pidx = (thi << (4 - j)) | ((unsigned)r0 >> (j + 1));
-            const TwPair W = tw[(1u << s) + pidx];
+            TwPair W;
+            if constexpr (B == Geo<LOGN>::B0)      // twiddle index does not depend on the thread: scalar load
+                W = tw[(1u << s) + ((unsigned)r0 >> (j + 1))];
+            else
+                W = buf_load_tw(twr, (thi << (4 - j)) * 16u, ((1u << s) + ((unsigned)r0 >> (j + 1))) * 16u);
             u64 U = v[r0];
             if (red) U = reduce_2q(U, p);
             const u64 Tm = mul_shoup<EX>(v[r1], W.w, W.wp, p.nq);
             v[r0] = U + Tm;
             v[r1] = U + cq - Tm;
+            if ((++cnt % SCHED_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 // Inverse (GS) stages on register bits JLO..4 of a layout with register field at bit B.
 template <int LOGN, int HL, int B, int JLO>
-__device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, unsigned t, const PrimeDev& p)
+__device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
     constexpr InvPolicy<LOGN, HL> POL{};
     constexpr bool EX = Lazy<HL>::EXACT;
     const unsigned thi = t >> B;
+    int cnt = 0;
 #pragma unroll
     for (int j = JLO; j <= 4; j++) {
         const int beta = B + j;                 // index bit of this stage
@@ -264,12 +337,16 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
                 v[r0] = mul_shoup<EX>(S, p.ninv, p.ninv_p, p.nq);
                 v[r1] = mul_shoup<EX>(D, p.w1n, p.w1n_p, p.nq);
             } else {
-                const unsigned pidx = (thi << (4 - j)) | ((unsigned)r0 >> (j + 1));
-                const TwPair W = tw[(1u << (LOGN - 1 - beta)) + pidx];
+                TwPair W;
+                if constexpr (B == Geo<LOGN>::B0)
+                    W = tw[(1u << (LOGN - 1 - beta)) + ((unsigned)r0 >> (j + 1))];
+                else
+                    W = buf_load_tw(twr, (thi << (4 - j)) * 16u, ((1u << (LOGN - 1 - beta)) + ((unsigned)r0 >> (j + 1))) * 16u);
                 if (red) S = reduce_2q(S, p);
                 v[r0] = S;
                 v[r1] = mul_shoup<EX>(D, W.w, W.wp, p.nq);
             }
+            if ((++cnt % SCHED_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -278,7 +355,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
 // whole transforms on registers.  Entry and exit layout: B0 (coalesced: i = (r << B0) | t).
 // ------------------------------------------------------------------------------------------------
 template <int LOGN, int HL, int RHO>
-__device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
+__device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds)
 {
     using G = Geo<LOGN>;
     if constexpr (RHO < G::NR) {
@@ -289,8 +366,8 @@ __device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, unsig
             constexpr int BP = TOPP - 4 > 0 ? TOPP - 4 : 0;
             exchange<LOGN, BP, B>(v, lds, t);
         }
-        ct_round<LOGN, HL, B, TOP - B>(v, tw, t, p);
-        fwd_rounds<LOGN, HL, RHO + 1>(v, tw, t, p, lds);
+        ct_round<LOGN, HL, B, TOP - B>(v, tw, twr, t, p);
+        fwd_rounds<LOGN, HL, RHO + 1>(v, tw, twr, t, p, lds);
     }
 }
 
@@ -298,11 +375,11 @@ __device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, unsig
 template <int LOGN, int HL>
 __device__ __forceinline__ void forward_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
 {
-    fwd_rounds<LOGN, HL, 0>(v, tw, t, p, lds);
+    fwd_rounds<LOGN, HL, 0>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
 }
 
 template <int LOGN, int HL, int RHO>
-__device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
+__device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds)
 {
     using G = Geo<LOGN>;
     if constexpr (RHO < G::NR) {
@@ -313,8 +390,8 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, unsig
             constexpr int BP = LOWP < G::B0 ? LOWP : G::B0;
             exchange<LOGN, BP, B>(v, lds, t);
         }
-        gs_round<LOGN, HL, B, LOW - B>(v, tw, t, p);
-        inv_rounds<LOGN, HL, RHO + 1>(v, tw, t, p, lds);
+        gs_round<LOGN, HL, B, LOW - B>(v, tw, twr, t, p);
+        inv_rounds<LOGN, HL, RHO + 1>(v, tw, twr, t, p, lds);
     }
 }
 
@@ -322,7 +399,7 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, unsig
 template <int LOGN, int HL>
 __device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
 {
-    inv_rounds<LOGN, HL, 0>(v, tw, t, p, lds);
+    inv_rounds<LOGN, HL, 0>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
 }
 
 template <int HL>
