@@ -87,15 +87,48 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         d.red_c = (u32)((((u128)1) << (31 + pp.k)) / pp.q);
     }
     const size_t words = (size_t)num_primes * n;
+    // device layout: stage blocks transposed per round (ntt_core.cuh, tw_dev_index); entry 0 is never read
     std::vector<TwPair> hf(words), hi(words);
-    for (unsigned i = 0; i < num_primes; i++)
-        for (unsigned j = 0; j < n; j++) {
-            const size_t o = (size_t)i * n + j;
-            hf[o].w = h_psi[o];
-            hf[o].wp = shoup(h_psi[o], prime[i].q);
-            hi[o].w = h_psiinv[o];
-            hi[o].wp = shoup(h_psiinv[o], prime[i].q);
+    const int logn = (int)t->log_n;
+    const bool sp = logn >= 11 && logn <= 15;           // sizes served by the single-pass kernels
+    for (unsigned i = 0; i < num_primes; i++) {
+        const u64 q = prime[i].q;
+        const size_t o = (size_t)i * n;
+        for (unsigned j = 0; j < n; j++) {              // default: reference order (also the fallback for other n)
+            hf[o + j] = TwPair{h_psi[o + j], shoup(h_psi[o + j], q)};
+            hi[o + j] = TwPair{h_psiinv[o + j], shoup(h_psiinv[o + j], q)};
         }
+        if (!sp) continue;
+        const int nr = (logn + 4) / 5;
+        for (int rho = 0; rho < nr; rho++) {
+            // forward round rho: index bits top .. B
+            {
+                const int top = logn - 1 - 5 * rho, B = top - 4 > 0 ? top - 4 : 0;
+                const unsigned nthi = (1u << (logn - 5)) >> B;
+                for (int j = top - B; j >= 0; j--) {
+                    const unsigned len = 1u << (logn - 1 - (B + j));
+                    for (unsigned thi = 0; thi < nthi; thi++)
+                        for (unsigned u = 0; u < (1u << (4 - j)) && ((thi << (4 - j)) + u) < len; u++) {
+                            const size_t src = o + len + (thi << (4 - j)) + u;
+                            hf[o + tw_dev_index(logn, B, j, len, thi, u)] = TwPair{h_psi[src], shoup(h_psi[src], q)};
+                        }
+                }
+            }
+            // inverse round rho: index bits low .. (B + 4)
+            {
+                const int low = 5 * rho, B = low < logn - 5 ? low : logn - 5;
+                const unsigned nthi = (1u << (logn - 5)) >> B;
+                for (int j = low - B; j <= 4; j++) {
+                    const unsigned len = 1u << (logn - 1 - (B + j));
+                    for (unsigned thi = 0; thi < nthi; thi++)
+                        for (unsigned u = 0; u < (1u << (4 - j)) && ((thi << (4 - j)) + u) < len; u++) {
+                            const size_t src = o + len + (thi << (4 - j)) + u;
+                            hi[o + tw_dev_index(logn, B, j, len, thi, u)] = TwPair{h_psiinv[src], shoup(h_psiinv[src], q)};
+                        }
+                }
+            }
+        }
+    }
     hipError_t e;
     if ((e = hipMalloc((void**)&t->d_fwd, words * sizeof(TwPair))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&t->d_inv, words * sizeof(TwPair))) != hipSuccess) return e;

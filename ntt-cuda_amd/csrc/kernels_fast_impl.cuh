@@ -12,6 +12,11 @@ namespace mi355ntt {
 template <int LOGN>
 __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restrict__ poly, unsigned t)
 {
+#ifdef MI355NTT_ABLATE_GLOBAL
+#pragma unroll
+    for (int r = 0; r < 32; r++) v[r] = (u64)t * 0x9E3779B97F4A7C15ULL + r;
+    return;
+#endif
     const BufRsrc rs = make_rsrc(poly, Geo<LOGN>::N * 8u);
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = buf_load_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u);
@@ -20,55 +25,82 @@ __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restri
 template <int LOGN>
 __device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restrict__ poly, unsigned t)
 {
+#ifdef MI355NTT_ABLATE_GLOBAL
+    u64 acc = 0;
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc ^= v[r];
+    if (acc == 0x123456789ULL) poly[t] = acc;
+    return;
+#endif
     const BufRsrc rs = make_rsrc(poly, Geo<LOGN>::N * 8u);
 #pragma unroll
     for (int r = 0; r < 32; r++) buf_store_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u, v[r]);
 }
 
+// Persistent workgroups: grid = min(num, resident workgroups); each workgroup walks polynomials
+// y = blockIdx.x, blockIdx.x + gridDim.x, ...  The loads of the next polynomial are issued right behind the
+// stores of the current one, so the write drain, the dispatch gap and the read latency overlap.
+
 // ---- forward: natural -> bit-reversed, canonical ------------------------------------------------
 template <int LOGN, int HL>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-          unsigned prime_base)
+          unsigned prime_base, unsigned num)
 {
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned y = blockIdx.x;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    u64* poly = a + (size_t)y * G::N;
     const unsigned t = threadIdx.x;
     u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
-    forward_core<LOGN, HL>(v, twp, t, p, lds);
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = canon_2q(reduce_2q(v[r], p), p.q);
-    exchange<LOGN, 0, G::B0>(v, lds, t);
-    store_coalesced<LOGN>(v, poly, t);
+    unsigned y = blockIdx.x;
+    MI355NTT_STAMP(15);
+    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    for (; y < num; y += gridDim.x) {
+        const unsigned idx = prime_base + y % division;
+        const PrimeDev p = primes[idx];
+        const TwPair* twp = tw + (size_t)idx * G::N;
+        u64* poly = a + (size_t)y * G::N;
+        MI355NTT_STAMP(0);
+        forward_core<LOGN, HL>(v, twp, t, p, lds);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q(v[decltype(rc)::value], p), p.q); });
+        MI355NTT_STAMP(6);
+        exchange<LOGN, 0, G::B0>(v, lds, t);
+        MI355NTT_STAMP(7);
+        store_coalesced<LOGN>(v, poly, t);
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        MI355NTT_STAMP(8);
+        __syncthreads();        // the next polynomial's first exchange reuses the LDS image
+    }
 }
 
 // ---- inverse: bit-reversed -> natural, scaled by n^-1, canonical --------------------------------
 template <int LOGN, int HL>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-          unsigned prime_base)
+          unsigned prime_base, unsigned num)
 {
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned y = blockIdx.x;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    u64* poly = a + (size_t)y * G::N;
     const unsigned t = threadIdx.x;
     u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
-    exchange<LOGN, G::B0, 0>(v, lds, t);
-    inverse_core<LOGN, HL>(v, twp, t, p, lds);
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL>(v[r], p);
-    store_coalesced<LOGN>(v, poly, t);
+    unsigned y = blockIdx.x;
+    MI355NTT_STAMP(15);
+    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    for (; y < num; y += gridDim.x) {
+        const unsigned idx = prime_base + y % division;
+        const PrimeDev p = primes[idx];
+        const TwPair* twp = tw + (size_t)idx * G::N;
+        u64* poly = a + (size_t)y * G::N;
+        MI355NTT_STAMP(0);
+        exchange<LOGN, G::B0, 0>(v, lds, t);
+        MI355NTT_STAMP(1);
+        inverse_core<LOGN, HL>(v, twp, t, p, lds);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+        MI355NTT_STAMP(8);
+        store_coalesced<LOGN>(v, poly, t);
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        MI355NTT_STAMP(9);
+        __syncthreads();
+    }
 }
 
 // ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
@@ -105,14 +137,34 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     store_coalesced<LOGN>(v, poly, t);
 }
 
+// Workgroups that can be resident at once: 256 CUs x (what 128 VGPRs/thread, the LDS image and 32 waves/CU admit).
+// A grid of at most that size makes every workgroup persistent; more polynomials are walked in-kernel.
+template <int LOGN>
+inline unsigned persistent_grid(unsigned num)
+{
+    using G = Geo<LOGN>;
+    const unsigned by_waves = 16u / (G::T / 64u);                                   // 4 waves/SIMD at 128 VGPRs
+    const unsigned by_lds = 163840u / (G::LDS_WORDS * 8u);
+    unsigned per_cu = by_waves < by_lds ? by_waves : by_lds;
+    if (per_cu < 1) per_cu = 1;
+    int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const unsigned cap = (unsigned)cus * per_cu;
+    return num < cap ? num : cap;
+}
+
 template <int LOGN>
 hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                       hipStream_t s)
 {
-    dim3 g(num), b(Geo<LOGN>::T);
-    if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
+    if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     return hipGetLastError();
 }
 
@@ -120,10 +172,10 @@ template <int LOGN>
 hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                       hipStream_t s)
 {
-    dim3 g(num), b(Geo<LOGN>::T);
-    if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
-    else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base);
+    dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
+    if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     return hipGetLastError();
 }
 

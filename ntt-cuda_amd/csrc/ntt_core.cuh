@@ -14,9 +14,41 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "modarith.cuh"
 
 namespace mi355ntt {
+
+// Compile-time loop: the body receives std::integral_constant<int, I>, so every register-array index below
+// is a constant expression (a runtime-indexed u64[32] would be placed in scratch memory).
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// Optional in-kernel phase stamps (diagnostic builds only: -DMI355NTT_STAMPS, tools/kbench.hip).  Stamp values
+// go to a buffer of their own and never feed an output.
+#ifdef MI355NTT_STAMPS
+__device__ unsigned long long* g_stamp_buf;
+__device__ __forceinline__ void stamp(int slot)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long tm;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if ((threadIdx.x & 63) == 0) g_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + slot] = tm;
+}
+#define MI355NTT_STAMP(slot) stamp(slot)
+#else
+#define MI355NTT_STAMP(slot)
+#endif
 
 // Per-prime constants, read with scalar loads (replaces __constant__ q_cons/mu_cons/q_bit_cons).
 struct PrimeDev {
@@ -33,6 +65,19 @@ struct PrimeDev {
 struct TwPair {       // {w, floor(w * 2^64 / q)}
     u64 w, wp;
 };
+
+// Device twiddle layout.  The reference table keeps stage `len` in entries [len, 2 len) indexed by the
+// butterfly group p = i >> (bit + 1).  A thread of a round whose register field sits at bit B needs, for the
+// stage on register bit j, the groups p = (thi << (4-j)) + u, u = 0 .. 2^(4-j)-1, thi = t >> B: for the
+// last round (B = 0) that is 2^(4-j) consecutive entries per lane, i.e. lanes 256 bytes apart.  The device
+// copy therefore stores each stage block transposed, entry len + u * nthi + thi (nthi = threads >> B), so
+// that consecutive lanes read consecutive 16-byte entries and the per-register part is a compile-time offset.
+__host__ __device__ constexpr unsigned tw_dev_index(int logn, int B, int j, unsigned len, unsigned thi, unsigned u)
+{
+    const unsigned nthi = (1u << (logn - 5)) >> B;
+    (void)j;
+    return len + u * nthi + thi;
+}
 
 // Buffer-descriptor loads/stores: one 32-bit lane offset VGPR serves every access of a thread, the
 // per-register displacement rides in the scalar offset / immediate (no 64-bit address arithmetic in VGPRs).
@@ -223,45 +268,60 @@ constexpr unsigned phase_of_reg(unsigned r)
 template <int LOGN, int BO, int BN>
 __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
 {
+#ifdef MI355NTT_ABLATE_EXCHANGE      // timing experiments only (tools/kbench.hip): results are wrong
+    return;
+#endif
     using G = Geo<LOGN>;
     constexpr int PH = G::TWO_PHASE ? 2 : 1;
     constexpr bool W_REG_SPLIT = G::TWO_PHASE && (G::PB >= BO && G::PB < BO + 5);   // phase bit is a writer register bit
     constexpr bool R_REG_SPLIT = G::TWO_PHASE && (G::PB >= BN && G::PB < BN + 5);   // phase bit is a reader register bit
     const unsigned w_phase = G::TWO_PHASE ? phase_of_thread<LOGN, BO>(t) : 0u;
     const unsigned r_phase = G::TWO_PHASE ? phase_of_thread<LOGN, BN>(t) : 0u;
-    u64* wbase = lds + slot_base<LOGN, BO>(t);
-    const u64* rbase = lds + slot_base<LOGN, BN>(t);
+    // DS instructions carry a 16-bit byte offset: address the (up to 136 KiB) image through up to three bases
+    // 64 KiB apart.  The asm fence keeps the bases local to this exchange (otherwise the compiler shares the
+    // per-access addresses between exchanges and spills them across the compute rounds in between).
+    constexpr unsigned SEG = 8192;                      // words per 64 KiB
+    unsigned ws0 = slot_base<LOGN, BO>(t), rs0 = slot_base<LOGN, BN>(t);
+    asm volatile("" : "+v"(ws0), "+v"(rs0));
+    unsigned ws1 = ws0 + SEG, ws2 = ws0 + 2 * SEG, rs1 = rs0 + SEG, rs2 = rs0 + 2 * SEG;
+    asm volatile("" : "+v"(ws1), "+v"(ws2), "+v"(rs1), "+v"(rs2));
+    u64* const wb[3] = {lds + ws0, lds + ws1, lds + ws2};
+    const u64* const rb[3] = {lds + rs0, lds + rs1, lds + rs2};
     u64 nv[32];
-#pragma unroll
-    for (int ph = 0; ph < PH; ph++) {
+    static_for<PH>([&](auto phc) {
+        constexpr unsigned ph = decltype(phc)::value;
         // ---- write ----
-        if (W_REG_SPLIT || !G::TWO_PHASE || w_phase == (unsigned)ph) {
-#pragma unroll
-            for (int r = 0; r < 32; r += (BO == 0 ? 2 : 1)) {
-                if (W_REG_SPLIT && phase_of_reg<LOGN, BO>(r) != (unsigned)ph) continue;
-                if constexpr (BO == 0)
-                    *reinterpret_cast<ulonglong2*>(wbase + slot_off<LOGN, BO>(r)) = make_ulonglong2(v[r], v[r + 1]);
-                else
-                    wbase[slot_off<LOGN, BO>(r)] = v[r];
-            }
+        if (W_REG_SPLIT || !G::TWO_PHASE || w_phase == ph) {
+            static_for<(BO == 0 ? 16 : 32)>([&](auto rc) {
+                constexpr int r = decltype(rc)::value * (BO == 0 ? 2 : 1);
+                if constexpr (!W_REG_SPLIT || phase_of_reg<LOGN, BO>(r) == ph) {
+                    constexpr unsigned off = slot_off<LOGN, BO>(r);
+                    if constexpr (BO == 0)
+                        *reinterpret_cast<ulonglong2*>(wb[off / SEG] + off % SEG) = make_ulonglong2(v[r], v[r + 1]);
+                    else
+                        wb[off / SEG][off % SEG] = v[r];
+                }
+            });
         }
         __syncthreads();
         // ---- read ----
-        if (R_REG_SPLIT || !G::TWO_PHASE || r_phase == (unsigned)ph) {
-#pragma unroll
-            for (int r = 0; r < 32; r += (BN == 0 ? 2 : 1)) {
-                if (R_REG_SPLIT && phase_of_reg<LOGN, BN>(r) != (unsigned)ph) continue;
-                if constexpr (BN == 0) {
-                    const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(rbase + slot_off<LOGN, BN>(r));
-                    nv[r] = pr.x;
-                    nv[r + 1] = pr.y;
-                } else {
-                    nv[r] = rbase[slot_off<LOGN, BN>(r)];
+        if (R_REG_SPLIT || !G::TWO_PHASE || r_phase == ph) {
+            static_for<(BN == 0 ? 16 : 32)>([&](auto rc) {
+                constexpr int r = decltype(rc)::value * (BN == 0 ? 2 : 1);
+                if constexpr (!R_REG_SPLIT || phase_of_reg<LOGN, BN>(r) == ph) {
+                    constexpr unsigned off = slot_off<LOGN, BN>(r);
+                    if constexpr (BN == 0) {
+                        const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(rb[off / SEG] + off % SEG);
+                        nv[r] = pr.x;
+                        nv[r + 1] = pr.y;
+                    } else {
+                        nv[r] = rb[off / SEG][off % SEG];
+                    }
                 }
-            }
+            });
         }
         __syncthreads();
-    }
+    });
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = nv[r];
 }
@@ -277,37 +337,65 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
 #endif
 constexpr int SCHED_GROUP = MI355NTT_SCHED_GROUP;
 
+// k-th register index (k = 0..15) whose bit j is clear
+__host__ __device__ constexpr int low_reg(int j, int k) { return ((k >> j) << (j + 1)) | (k & ((1 << j) - 1)); }
+
+// Twiddles of butterfly group G of a round (GROUP butterflies per group, 16 / GROUP groups per stage).
+// FWD: stages run j = JA, JA-1, ...; INV: j = JA, JA+1, ...
+template <int LOGN, int B, int JA, bool FWD, int GROUP, int G>
+__device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* __restrict__ tw, BufRsrc twr, unsigned thi)
+{
+    constexpr int GPS = 16 / GROUP;                         // groups per stage
+    constexpr int j = FWD ? JA - G / GPS : JA + G / GPS;
+    constexpr int beta = B + j;                             // index bit of the stage
+    constexpr unsigned len = 1u << (LOGN - 1 - beta);
+    static_for<GROUP>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int r0 = low_reg(j, (G % GPS) * GROUP + k);
+        constexpr unsigned u = (unsigned)r0 >> (j + 1);
+#ifdef MI355NTT_ABLATE_TWIDDLE
+        W[k].w = 0x123456789abcdefULL + r0; W[k].wp = 0xfedcba987654321ULL + j; (void)tw; (void)twr; (void)thi;
+#else
+        if constexpr (B == Geo<LOGN>::B0)                   // group index independent of the thread: scalar load
+            W[k] = tw[len + u];
+        else
+            W[k] = buf_load_tw(twr, thi * 16u, tw_dev_index(LOGN, B, j, len, 0, u) * 16u);
+#endif
+    });
+}
+
 // Forward (CT) stages on register bits JHI..0 of a layout with register field at bit B.
-// S0 = global stage number of the first stage in this round.
 template <int LOGN, int HL, int B, int JHI>
 __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
     constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
     constexpr bool EX = Lazy<HL>::EXACT;
+    constexpr int GROUP = SCHED_GROUP, GPS = 16 / GROUP, NG = (JHI + 1) * GPS;
+    constexpr bool VEC = (B != Geo<LOGN>::B0);              // twiddles arrive in VGPRs: software-pipeline them one group ahead
     const u64 cq = (u64)Lazy<HL>::TQ * p.q;
     const unsigned thi = t >> B;
-    int cnt = 0;
-#pragma unroll
-    for (int j = JHI; j >= 0; j--) {
-        const int s = LOGN - 1 - (B + j);
-        const bool red = (RMASK >> s) & 1u;
-#pragma unroll
-        for (int r0 = 0; r0 < 32; r0++) {
-            if (r0 & (1 << j)) continue;
-            const int r1 = r0 | (1 << j);
-            TwPair W;
-            if constexpr (B == Geo<LOGN>::B0)      // twiddle index does not depend on the thread: scalar load
-                W = tw[(1u << s) + ((unsigned)r0 >> (j + 1))];
-            else
-                W = buf_load_tw(twr, (thi << (4 - j)) * 16u, ((1u << s) + ((unsigned)r0 >> (j + 1))) * 16u);
+    TwPair Wc[GROUP], Wn[GROUP];
+    load_tw_group<LOGN, B, JHI, true, GROUP, 0>(Wc, tw, twr, thi);
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int j = JHI - g / GPS;
+        constexpr int s = LOGN - 1 - (B + j);
+        constexpr bool red = (RMASK >> s) & 1u;
+        if constexpr (g + 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + 1>(Wn, tw, twr, thi);
+        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+        static_for<GROUP>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
+            constexpr int r1 = r0 | (1 << j);
             u64 U = v[r0];
-            if (red) U = reduce_2q(U, p);
-            const u64 Tm = mul_shoup<EX>(v[r1], W.w, W.wp, p.nq);
+            if constexpr (red) U = reduce_2q(U, p);
+            const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
             v[r0] = U + Tm;
             v[r1] = U + cq - Tm;
-            if ((++cnt % SCHED_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+        });
+        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g + 1 < NG) static_for<GROUP>([&](auto kc) { Wc[decltype(kc)::value] = Wn[decltype(kc)::value]; });
+    });
 }
 
 // Inverse (GS) stages on register bits JLO..4 of a layout with register field at bit B.
@@ -316,39 +404,40 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
 {
     constexpr InvPolicy<LOGN, HL> POL{};
     constexpr bool EX = Lazy<HL>::EXACT;
+    constexpr int GROUP = SCHED_GROUP, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
+    constexpr bool VEC = (B != Geo<LOGN>::B0);
     const unsigned thi = t >> B;
-    int cnt = 0;
-#pragma unroll
-    for (int j = JLO; j <= 4; j++) {
-        const int beta = B + j;                 // index bit of this stage
-        const int s = beta;                     // GS stage number (0 = first)
-        const bool last = (beta == LOGN - 1);
-        const bool red = (POL.mask >> s) & 1u;
-        const u64 cq = (u64)POL.cmul[s] * p.q;
-#pragma unroll
-        for (int r0 = 0; r0 < 32; r0++) {
-            if (r0 & (1 << j)) continue;
-            const int r1 = r0 | (1 << j);
+    TwPair Wc[GROUP], Wn[GROUP];
+    load_tw_group<LOGN, B, JLO, false, GROUP, 0>(Wc, tw, twr, thi);
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int j = JLO + g / GPS;
+        constexpr int beta = B + j;             // index bit of this stage = GS stage number (0 = first)
+        constexpr bool last = (beta == LOGN - 1);
+        constexpr bool red = (POL.mask >> beta) & 1u;
+        const u64 cq = (u64)POL.cmul[beta] * p.q;
+        if constexpr (g + 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + 1>(Wn, tw, twr, thi);
+        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+        static_for<GROUP>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
+            constexpr int r1 = r0 | (1 << j);
             const u64 X = v[r0], Y = v[r1];
             u64 S = X + Y;
             const u64 D = X + cq - Y;
-            if (last) {
+            if constexpr (last) {
                 // length = 1: single twiddle, n^-1 folded into both outputs (the reference halves every stage)
                 v[r0] = mul_shoup<EX>(S, p.ninv, p.ninv_p, p.nq);
                 v[r1] = mul_shoup<EX>(D, p.w1n, p.w1n_p, p.nq);
             } else {
-                TwPair W;
-                if constexpr (B == Geo<LOGN>::B0)
-                    W = tw[(1u << (LOGN - 1 - beta)) + ((unsigned)r0 >> (j + 1))];
-                else
-                    W = buf_load_tw(twr, (thi << (4 - j)) * 16u, ((1u << (LOGN - 1 - beta)) + ((unsigned)r0 >> (j + 1))) * 16u);
-                if (red) S = reduce_2q(S, p);
+                if constexpr (red) S = reduce_2q(S, p);
                 v[r0] = S;
-                v[r1] = mul_shoup<EX>(D, W.w, W.wp, p.nq);
+                v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
             }
-            if ((++cnt % SCHED_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+        });
+        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g + 1 < NG) static_for<GROUP>([&](auto kc) { Wc[decltype(kc)::value] = Wn[decltype(kc)::value]; });
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,8 +454,10 @@ __device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             constexpr int TOPP = LOGN - 1 - 5 * (RHO - 1);
             constexpr int BP = TOPP - 4 > 0 ? TOPP - 4 : 0;
             exchange<LOGN, BP, B>(v, lds, t);
+            MI355NTT_STAMP(2 * RHO);
         }
         ct_round<LOGN, HL, B, TOP - B>(v, tw, twr, t, p);
+        MI355NTT_STAMP(2 * RHO + 1);
         fwd_rounds<LOGN, HL, RHO + 1>(v, tw, twr, t, p, lds);
     }
 }
@@ -389,8 +480,10 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             constexpr int LOWP = 5 * (RHO - 1);
             constexpr int BP = LOWP < G::B0 ? LOWP : G::B0;
             exchange<LOGN, BP, B>(v, lds, t);
+            MI355NTT_STAMP(2 * RHO + 2);
         }
         gs_round<LOGN, HL, B, LOW - B>(v, tw, twr, t, p);
+        MI355NTT_STAMP(2 * RHO + 3);
         inv_rounds<LOGN, HL, RHO + 1>(v, tw, twr, t, p, lds);
     }
 }

@@ -1,0 +1,91 @@
+// kbench.hip -- standalone timing of the single-pass kernels (n = 2^15) with optional ablations
+// (-DMI355NTT_ABLATE_EXCHANGE / _TWIDDLE / _GLOBAL: results are wrong, timing only).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ntt-cuda_amd/csrc -I include [-D...] tools/kbench.hip \
+//         ntt-cuda_amd/csrc/hostparams.cpp -o tools/kbench_X
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kernels_fast_impl.cuh"
+
+using namespace mi355ntt;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv)
+{
+    const int LOGN = 15;
+    const unsigned n = 1u << LOGN;
+    unsigned num = argc > 1 ? atoi(argv[1]) : 1024;
+    int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const u64 q = 1152921504606584833ULL, psi = 4443670208963ULL;
+    PrimeParams pp;
+    if (derive_prime(n, q, psi, &pp)) { printf("bad prime\n"); return 1; }
+    std::vector<u64> tab(n);
+    fill_table(psi, q, n, tab.data());
+    std::vector<TwPair> tw(n);
+    for (unsigned i = 0; i < n; i++) tw[i] = TwPair{tab[i], shoup(tab[i], q)};   // layout irrelevant for timing
+    PrimeDev d{};
+    d.q = q; d.nq = 0ULL - q; d.ninv = pp.ninv; d.ninv_p = shoup(pp.ninv, q); d.w1n = 12345; d.w1n_p = shoup(12345, q);
+    d.mu = pp.mu; d.k = pp.k; d.red_sh1 = pp.k - 17; d.red_sh2 = 16; d.red_c = (u32)((((u128)1) << (31 + pp.k)) / q);
+    u64* a; TwPair* dtw; PrimeDev* dp;
+    CK(hipMalloc(&a, (size_t)num * n * 8));
+    CK(hipMalloc(&dtw, n * sizeof(TwPair)));
+    CK(hipMalloc(&dp, sizeof(PrimeDev)));
+    std::vector<u64> h((size_t)num * n);
+    u64 x = 88172645463325252ULL;
+    for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = x % q; }
+    CK(hipMemcpy(a, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtw, tw.data(), n * sizeof(TwPair), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dp, &d, sizeof(d), hipMemcpyHostToDevice));
+#ifdef MI355NTT_STAMPS
+    unsigned long long* dstamp;
+    CK(hipMalloc(&dstamp, (size_t)num * 16 * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dstamp, sizeof(dstamp)));
+#endif
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int which = 0; which < 2; which++) {
+        for (int i = 0; i < 3; i++) {
+            if (which == 0) launch_fwd<LOGN>(4, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(4, a, dtw, dp, num, 1, 0, 0);
+        }
+        CK(hipDeviceSynchronize());
+        std::vector<float> ts;
+        for (int i = 0; i < reps; i++) {
+            CK(hipEventRecord(e0));
+            if (which == 0) launch_fwd<LOGN>(4, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(4, a, dtw, dp, num, 1, 0, 0);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+        }
+        std::sort(ts.begin(), ts.end());
+#ifdef MI355NTT_STAMPS
+        {
+            std::vector<unsigned long long> st((size_t)num * 256);
+            CK(hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost));
+            // forward slots: 15 start,0 load,1 R1,2 E1,3 R2,4 E2,5 R3,6 canon,7 E3,8 store ; inverse: 15,0 load,1 E0,3 R1,4 E1,5 R2,6 E2,7 R3,8 canon,9 store
+            const int seqf[] = {15, 0, 1, 2, 3, 4, 5, 6, 7, 8};
+            const char* nmf[] = {"load", "R1", "E1", "R2", "E2", "R3", "canon", "E3", "store"};
+            const int seqi[] = {15, 0, 1, 3, 4, 5, 6, 7, 8, 9};
+            const char* nmi[] = {"load", "E0", "R1", "E1", "R2", "E2", "R3+canon", "-", "store"};
+            const int* seq = which ? seqi : seqf;
+            const char** nm = which ? nmi : nmf;
+            double tot = 0;
+            for (int ph = 0; ph < 9; ph++) {
+                double acc = 0;
+                for (size_t w = 0; w < (size_t)num * 16; w++) acc += (double)(st[w * 16 + seq[ph + 1]] - st[w * 16 + seq[ph]]);
+                acc /= (double)num * 16;
+                tot += acc;
+                printf("    %-9s %9.0f cycles\n", nm[ph], acc);
+            }
+            printf("    total     %9.0f cycles per wave lifetime (stamped build)\n", tot);
+        }
+#endif
+        printf("%s  num=%u  median %.4f ms  min %.4f ms  => %.3f M transforms/s  (%.1f%% of 15.26M)\n", which ? "inverse" : "forward", num,
+               ts[ts.size() / 2], ts[0], num / (ts[ts.size() / 2] * 1e-3) / 1e6, num / (ts[ts.size() / 2] * 1e-3) / 15.26e6 * 100);
+    }
+    return 0;
+}
