@@ -103,6 +103,129 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     }
 }
 
+// ================================================================================================
+// n = 2^15: one workgroup-wide exchange per transform, everything else wave-local (ntt_core.cuh).
+// forward : load(layout 10) R1 | sync, exchange 10->5 | R2 | wave transpose 5->0 | R3 | canon | wave-local row store
+// inverse : wave-local row load (layout 0) | R1' | wave transpose 0->5 | R2' | sync, exchange 5->10 | R3' | canon | store
+// ================================================================================================
+template <int HL>
+__global__ void __launch_bounds__(1024, 4)
+k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+            unsigned prime_base, unsigned num)
+{
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    u64* slice = lds + wave * WAVE_SLICE_WORDS;
+    u64 v[32];
+    unsigned y = blockIdx.x;
+    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    for (; y < num; y += gridDim.x) {
+        const unsigned idx = prime_base + y % division;
+        const PrimeDev p = primes[idx];
+        const TwPair* twp = tw + (size_t)idx * G::N;
+        const BufRsrc twr = make_rsrc(twp, G::N * 16u);
+        u64* poly = a + (size_t)y * G::N;
+        ct_round<LOGN, HL, 10, 4>(v, twp, twr, t, p);
+        __syncthreads();                                  // every wave has left its private slice (previous polynomial)
+        exchange<LOGN, 10, 5>(v, lds, t);
+        ct_round<LOGN, HL, 5, 4>(v, twp, twr, t, p);
+        wave_transpose_5_to_0(v, slice, lane);
+        ct_round<LOGN, HL, 0, 4>(v, twp, twr, t, p);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q(v[decltype(rc)::value], p), p.q); });
+        wave_store_rows(v, slice, make_rsrc(poly, G::N * 8u), wave * 16384u, lane);
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+    }
+}
+
+template <int HL>
+__global__ void __launch_bounds__(1024, 4)
+k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+            unsigned prime_base, unsigned num)
+{
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    u64* slice = lds + wave * WAVE_SLICE_WORDS;
+    u64 v[32];
+    unsigned y = blockIdx.x;
+    wave_load_rows(v, slice, make_rsrc(a + (size_t)y * G::N, G::N * 8u), wave * 16384u, lane);
+    for (; y < num; y += gridDim.x) {
+        const unsigned idx = prime_base + y % division;
+        const PrimeDev p = primes[idx];
+        const TwPair* twp = tw + (size_t)idx * G::N;
+        const BufRsrc twr = make_rsrc(twp, G::N * 16u);
+        u64* poly = a + (size_t)y * G::N;
+        gs_round<LOGN, HL, 0, 0>(v, twp, twr, t, p);
+        wave_transpose_0_to_5(v, slice, lane);
+        gs_round<LOGN, HL, 5, 0>(v, twp, twr, t, p);
+        __syncthreads();                                  // private slices are idle from here on
+        exchange<LOGN, 5, 10>(v, lds, t);
+        gs_round<LOGN, HL, 10, 0>(v, twp, twr, t, p);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+        store_coalesced<LOGN>(v, poly, t);
+        if (y + gridDim.x < num)
+            wave_load_rows(v, slice, make_rsrc(a + (size_t)(y + gridDim.x) * G::N, G::N * 8u), wave * 16384u, lane);
+    }
+}
+
+template <int HL>
+__global__ void __launch_bounds__(1024, 4)
+k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
+            const PrimeDev* __restrict__ primes, unsigned division, unsigned num)
+{
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    u64* slice = lds + wave * WAVE_SLICE_WORDS;
+    u64 v[32];
+    unsigned y = blockIdx.x;
+    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    for (; y < num; y += gridDim.x) {
+        const unsigned idx = y % division;
+        const PrimeDev p = primes[idx];
+        const TwPair* tf = twf + (size_t)idx * G::N;
+        const TwPair* ti = twi + (size_t)idx * G::N;
+        const BufRsrc tfr = make_rsrc(tf, G::N * 16u), tir = make_rsrc(ti, G::N * 16u);
+        u64* poly = a + (size_t)y * G::N;
+        const BufRsrc brs = make_rsrc(bhat + (size_t)y * G::N, G::N * 8u);
+        // ---- forward ----
+        ct_round<LOGN, HL, 10, 4>(v, tf, tfr, t, p);
+        __syncthreads();
+        exchange<LOGN, 10, 5>(v, lds, t);
+        ct_round<LOGN, HL, 5, 4>(v, tf, tfr, t, p);
+        wave_transpose_5_to_0(v, slice, lane);
+        ct_round<LOGN, HL, 0, 4>(v, tf, tfr, t, p);
+        // ---- pointwise product with bhat, streamed 16 words per lane at a time (layout 0 on both sides) ----
+        {
+            u64 bb[16];
+            wave_load_rows_half<0>(bb, slice, brs, wave * 16384u, lane);
+            static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                v[r] = barrett_mul(canon_2q(reduce_2q(v[r], p), p.q), bb[r], p.q, p.mu, p.k);   // poly_arithmetic.cuh:36-66
+            });
+            wave_load_rows_half<1>(bb, slice, brs, wave * 16384u, lane);
+            static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                v[16 + r] = barrett_mul(canon_2q(reduce_2q(v[16 + r], p), p.q), bb[r], p.q, p.mu, p.k);
+            });
+        }
+        // ---- inverse ----
+        gs_round<LOGN, HL, 0, 0>(v, ti, tir, t, p);
+        wave_transpose_0_to_5(v, slice, lane);
+        gs_round<LOGN, HL, 5, 0>(v, ti, tir, t, p);
+        __syncthreads();
+        exchange<LOGN, 5, 10>(v, lds, t);
+        gs_round<LOGN, HL, 10, 0>(v, ti, tir, t, p);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+        store_coalesced<LOGN>(v, poly, t);
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+    }
+}
+
 // ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
 template <int LOGN, int HL>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
@@ -162,6 +285,12 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
                       hipStream_t s)
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
+    if constexpr (LOGN == 15) {
+        if (hl >= 6) k_forward15<6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else if (hl >= 4) k_forward15<4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_forward15<2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        return hipGetLastError();
+    }
     if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -173,6 +302,12 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
                       hipStream_t s)
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
+    if constexpr (LOGN == 15) {
+        if (hl >= 6) k_inverse15<6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else if (hl >= 4) k_inverse15<4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_inverse15<2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        return hipGetLastError();
+    }
     if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -183,6 +318,13 @@ template <int LOGN>
 hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr, unsigned num,
                       unsigned division, hipStream_t s)
 {
+    if constexpr (LOGN == 15) {
+        dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
+        if (hl >= 6) k_polymul15<6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        else if (hl >= 4) k_polymul15<4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        else k_polymul15<2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        return hipGetLastError();
+    }
     dim3 g(num), b(Geo<LOGN>::T);
     if (hl >= 6) k_polymul<LOGN, 6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
     else if (hl >= 4) k_polymul<LOGN, 4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);

@@ -85,9 +85,14 @@ typedef u32 v2u32 __attribute__((ext_vector_type(2)));
 typedef u32 v4u32 __attribute__((ext_vector_type(4)));
 using BufRsrc = __amdgpu_buffer_rsrc_t;
 
+// `base` must be wave-uniform (it always derives from kernel arguments and the polynomial index).  The
+// readfirstlane makes that provable to the compiler; otherwise every buffer access is wrapped in a
+// serialising "waterfall" loop.
 __device__ __forceinline__ BufRsrc make_rsrc(const void* base, u32 bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+    const u64 b = reinterpret_cast<u64>(base);
+    const u32 lo = __builtin_amdgcn_readfirstlane(lo32(b)), hi = __builtin_amdgcn_readfirstlane(hi32(b));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((u64)hi << 32) | lo), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ u64 buf_load_u64(BufRsrc r, u32 voff, u32 soff)
 {
@@ -210,7 +215,7 @@ struct Geo {
     static constexpr bool TWO_PHASE = (N * 8 > 131072);   // LDS holds half a 2^15 polynomial at a time
     static constexpr int PB = LOGN - 1;               // index bit that selects the phase
     static constexpr int ROWS = (TWO_PHASE ? N / 2 : N) / 32;
-    static constexpr int LDS_WORDS = ROWS * 34;       // 32 columns + 2 words (16 B) of padding per row
+    static constexpr int LDS_WORDS = (LOGN == 15) ? 16 * 1152 : ROWS * 34;   // image (32 + 2 pad words per row); n = 2^15: 16 wave slices of 9216 B
 };
 
 // element index held by thread t in register r for a layout whose register field sits at bit B
@@ -221,67 +226,38 @@ __device__ __forceinline__ unsigned elem_index(unsigned t, unsigned r)
 }
 
 // LDS image: element i lives at row (i' >> 5), column (i' & 31) of a [ROWS][34] array of u64 (two words of
-// padding per row keep 8- and 16-byte accesses conflict-free for every layout), where i' = i without the
-// phase bit.  For a layout with register field at bit B the slot splits into a per-thread base and a
-// per-register COMPILE-TIME offset, so every access is base VGPR + immediate.
-template <int LOGN, int B>
-__device__ __forceinline__ unsigned slot_base(unsigned t)
+// padding per row keep 8- and 16-byte accesses conflict-free for every layout).  When the image holds only
+// half a polynomial (n = 2^15) the exchange runs in two phases selected by index bit PB, and i' is i with
+// that bit removed.  Because the thread part and the register part of an index occupy disjoint bits, the
+// slot splits into a per-thread base and a per-register COMPILE-TIME offset: base VGPR + immediate.
+template <int PB>
+__host__ __device__ constexpr unsigned drop_bit(unsigned i)
 {
-    using G = Geo<LOGN>;
-    unsigned thi = t >> B, tlo = t & ((1u << B) - 1u);
-    if constexpr (B >= 5) {
-        unsigned i = (thi << (B + 5)) | tlo;                      // register field zero
-        if constexpr (G::TWO_PHASE) i &= (1u << G::PB) - 1u;
-        return (i >> 5) * 34u + (i & 31u);
-    } else {
-        unsigned row = thi << B;                                  // + (r >> (5-B)) from the register
-        if constexpr (G::TWO_PHASE) row &= (1u << (G::PB - 5)) - 1u;
-        return row * 34u + tlo;
-    }
+    if (PB < 0) return i;
+    return ((i >> (PB + 1)) << PB) | (i & ((1u << PB) - 1u));
 }
-
-template <int LOGN, int B>
-constexpr unsigned slot_off(unsigned r)
-{
-    using G = Geo<LOGN>;
-    if (B >= 5) {
-        unsigned c = r << B;
-        if (G::TWO_PHASE) c &= (1u << G::PB) - 1u;
-        return (c >> 5) * 34u;
-    }
-    return (r >> (5 - B)) * 34u + ((r & ((1u << (5 - B)) - 1u)) << B);
-}
-
-// which phase a (thread, register) element belongs to: the top index bit
-template <int LOGN, int B>
-__device__ __forceinline__ unsigned phase_of_thread(unsigned t)
-{
-    return (elem_index<B>(t, 0) >> Geo<LOGN>::PB) & 1u;
-}
-template <int LOGN, int B>
-constexpr unsigned phase_of_reg(unsigned r)
-{
-    return ((r << B) >> Geo<LOGN>::PB) & 1u;
-}
+__host__ __device__ constexpr unsigned slot_of(unsigned ip) { return (ip >> 5) * 34u + (ip & 31u); }
 
 // Transposition through LDS: registers hold layout BO on entry, layout BN on exit.
+// Two-phase case: the phase bit is the TOP REGISTER BIT OF THE READER layout, so every thread reads half of its
+// registers in each phase (no divergent register definitions); writers take part in the phase their element
+// belongs to (by register when the bit is in their register field, otherwise by thread).
 template <int LOGN, int BO, int BN>
 __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
 {
 #ifdef MI355NTT_ABLATE_EXCHANGE      // timing experiments only (tools/kbench.hip): results are wrong
     return;
 #endif
+    __builtin_amdgcn_sched_barrier(0);   // keep the next round's twiddle loads (and anything else) out of the exchange
     using G = Geo<LOGN>;
     constexpr int PH = G::TWO_PHASE ? 2 : 1;
-    constexpr bool W_REG_SPLIT = G::TWO_PHASE && (G::PB >= BO && G::PB < BO + 5);   // phase bit is a writer register bit
-    constexpr bool R_REG_SPLIT = G::TWO_PHASE && (G::PB >= BN && G::PB < BN + 5);   // phase bit is a reader register bit
-    const unsigned w_phase = G::TWO_PHASE ? phase_of_thread<LOGN, BO>(t) : 0u;
-    const unsigned r_phase = G::TWO_PHASE ? phase_of_thread<LOGN, BN>(t) : 0u;
+    constexpr int PB = G::TWO_PHASE ? BN + 4 : -1;
+    constexpr bool W_REG_SPLIT = G::TWO_PHASE && (PB >= BO && PB < BO + 5);
+    const unsigned w_phase = G::TWO_PHASE ? ((elem_index<BO>(t, 0) >> (PB < 0 ? 0 : PB)) & 1u) : 0u;
     // DS instructions carry a 16-bit byte offset: address the (up to 136 KiB) image through up to three bases
-    // 64 KiB apart.  The asm fence keeps the bases local to this exchange (otherwise the compiler shares the
-    // per-access addresses between exchanges and spills them across the compute rounds in between).
+    // 64 KiB apart.  The asm fences keep the bases local to this exchange.
     constexpr unsigned SEG = 8192;                      // words per 64 KiB
-    unsigned ws0 = slot_base<LOGN, BO>(t), rs0 = slot_base<LOGN, BN>(t);
+    unsigned ws0 = slot_of(drop_bit<PB>(elem_index<BO>(t, 0))), rs0 = slot_of(drop_bit<PB>(elem_index<BN>(t, 0)));
     asm volatile("" : "+v"(ws0), "+v"(rs0));
     unsigned ws1 = ws0 + SEG, ws2 = ws0 + 2 * SEG, rs1 = rs0 + SEG, rs2 = rs0 + 2 * SEG;
     asm volatile("" : "+v"(ws1), "+v"(ws2), "+v"(rs1), "+v"(rs2));
@@ -294,8 +270,8 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
         if (W_REG_SPLIT || !G::TWO_PHASE || w_phase == ph) {
             static_for<(BO == 0 ? 16 : 32)>([&](auto rc) {
                 constexpr int r = decltype(rc)::value * (BO == 0 ? 2 : 1);
-                if constexpr (!W_REG_SPLIT || phase_of_reg<LOGN, BO>(r) == ph) {
-                    constexpr unsigned off = slot_off<LOGN, BO>(r);
+                if constexpr (!W_REG_SPLIT || ((((unsigned)r << BO) >> (PB < 0 ? 0 : PB)) & 1u) == ph) {
+                    constexpr unsigned off = slot_of(drop_bit<PB>((unsigned)r << BO));
                     if constexpr (BO == 0)
                         *reinterpret_cast<ulonglong2*>(wb[off / SEG] + off % SEG) = make_ulonglong2(v[r], v[r + 1]);
                     else
@@ -304,26 +280,154 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
             });
         }
         __syncthreads();
-        // ---- read ----
-        if (R_REG_SPLIT || !G::TWO_PHASE || r_phase == ph) {
-            static_for<(BN == 0 ? 16 : 32)>([&](auto rc) {
-                constexpr int r = decltype(rc)::value * (BN == 0 ? 2 : 1);
-                if constexpr (!R_REG_SPLIT || phase_of_reg<LOGN, BN>(r) == ph) {
-                    constexpr unsigned off = slot_off<LOGN, BN>(r);
-                    if constexpr (BN == 0) {
-                        const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(rb[off / SEG] + off % SEG);
-                        nv[r] = pr.x;
-                        nv[r + 1] = pr.y;
-                    } else {
-                        nv[r] = rb[off / SEG][off % SEG];
-                    }
+        // ---- read: registers whose top bit equals the phase (all of them in the single-phase case) ----
+        static_for<(BN == 0 ? 16 : 32)>([&](auto rc) {
+            constexpr int r = decltype(rc)::value * (BN == 0 ? 2 : 1);
+            if constexpr (!G::TWO_PHASE || (unsigned)(r >> 4) == ph) {
+                constexpr unsigned off = slot_of(drop_bit<PB>((unsigned)r << BN));
+                if constexpr (BN == 0) {
+                    const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(rb[off / SEG] + off % SEG);
+                    nv[r] = pr.x;
+                    nv[r + 1] = pr.y;
+                } else {
+                    nv[r] = rb[off / SEG][off % SEG];
                 }
-            });
-        }
+            }
+        });
         __syncthreads();
     });
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = nv[r];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-local transposes (n = 2^15 path): no workgroup barrier, every wave uses a private 8704-byte slice
+// of the LDS image, so between two workgroup-wide exchanges the 16 waves run freely and their memory,
+// LDS and VALU phases overlap.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned WAVE_SLICE_WORDS = 1152;     // 2 half-waves x 32 rows x 18 words = 9216 B per wave (16 slices = 144 KiB)
+
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// layout 5 -> layout 0.  Per half-wave (32 lanes) this is a 32x32 transpose: lane (h, c) holds M[r][c] in register r
+// and ends with row (its own c): M[c][0..31].  Two steps of 16 COLUMNS each: the lanes owning those columns store
+// all their registers (an exec-masked store), then every lane loads 16 words of its row.
+__device__ __forceinline__ void wave_transpose_5_to_0(u64 (&v)[32], u64* slice, unsigned lane)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned h = lane >> 5, c = lane & 31;
+    u64* wcol = slice + h * 576 + (c & 15);                // [h][row 0..31][16 cols], row stride 18 words
+    const u64* rrow = slice + h * 576 + c * 18;
+    u64 nv[32];
+    static_for<2>([&](auto sc) {
+        constexpr int step = decltype(sc)::value;
+        if ((c >> 4) == (unsigned)step) {
+            static_for<32>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                wcol[r * 18] = v[r];
+            });
+        }
+        wave_lds_fence();
+        static_for<8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(rrow + 2 * m);
+            nv[16 * step + 2 * m] = pr.x;
+            nv[16 * step + 2 * m + 1] = pr.y;
+        });
+        wave_lds_fence();
+    });
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = nv[decltype(rc)::value]; });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// layout 0 -> layout 5 (the inverse direction)
+__device__ __forceinline__ void wave_transpose_0_to_5(u64 (&v)[32], u64* slice, unsigned lane)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned h = lane >> 5, c = lane & 31;
+    u64* wrow = slice + h * 544 + (c & 15) * 34;
+    const u64* rcol = slice + h * 544 + c;
+    u64 nv[32];
+    static_for<2>([&](auto sc) {
+        constexpr int step = decltype(sc)::value;
+        if ((c >> 4) == (unsigned)step) {
+            static_for<16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                *reinterpret_cast<ulonglong2*>(wrow + 2 * m) = make_ulonglong2(v[2 * m], v[2 * m + 1]);
+            });
+        }
+        wave_lds_fence();
+        static_for<16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            nv[16 * step + r] = rcol[r * 34];
+        });
+        wave_lds_fence();
+    });
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = nv[decltype(rc)::value]; });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Layout 0 <-> global memory with 16-byte accesses.  A wave owns 2048 consecutive coefficients (16 KiB): lane L
+// holds row L (32 words).  Going through the slice in two column halves of 128 B per row lets every global
+// instruction move 8 rows x 128 contiguous bytes.  16-byte slots are XOR-swizzled with the row so both the row
+// accesses (lane = row) and the transposed accesses (8 lanes per row) are bank-conflict free.
+__device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, BufRsrc dst, unsigned wave_byte_off, unsigned lane)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    char* base = reinterpret_cast<char*>(slice);
+    const unsigned sw = lane & 7, rr = lane >> 3;
+    static_for<2>([&](auto cc) {
+        constexpr int ch = decltype(cc)::value;
+        static_for<8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            *reinterpret_cast<ulonglong2*>(base + lane * 128 + ((m ^ sw) << 4)) = make_ulonglong2(v[16 * ch + 2 * m], v[16 * ch + 2 * m + 1]);
+        });
+        wave_lds_fence();
+        static_for<8>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            // row 8k + rr, piece (lane & 7): stored at slot piece ^ (row & 7) = sw ^ rr
+            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + (8 * k + rr) * 128 + ((sw ^ rr) << 4));
+            v4u32 x;
+            x.x = lo32(pr.x); x.y = hi32(pr.x); x.z = lo32(pr.y); x.w = hi32(pr.y);
+            __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, 0);
+        });
+        wave_lds_fence();
+    });
+}
+
+// one column half (CH = 0/1): 16 words of this lane's row into out[0..15]
+template <int CH>
+__device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
+{
+    char* base = reinterpret_cast<char*>(slice);
+    const unsigned sw = lane & 7, rr = lane >> 3;
+    v4u32 x[8];
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        x[k] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + CH * 128u, 0);
+    });
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ rr) << 4)) = x[k];
+    });
+    wave_lds_fence();
+    static_for<8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + lane * 128 + ((m ^ sw) << 4));
+        out[2 * m] = pr.x;
+        out[2 * m + 1] = pr.y;
+    });
+    wave_lds_fence();
+}
+
+__device__ __forceinline__ void wave_load_rows(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
+{
+    u64 h[16];
+    wave_load_rows_half<0>(h, slice, src, wave_byte_off, lane);
+    static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
+    wave_load_rows_half<1>(h, slice, src, wave_byte_off, lane);
+    static_for<16>([&](auto rc) { v[16 + decltype(rc)::value] = h[decltype(rc)::value]; });
 }
 
 // ------------------------------------------------------------------------------------------------
