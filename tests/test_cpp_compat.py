@@ -1,0 +1,33 @@
+"""The reference's own smoke test (60bit_ntt_test.cu, check = 1) rebuilt on the C++ compat headers."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "ntt_test_60bit.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "ntt_test_60bit")
+
+
+def build(native, oracle):
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(SRC):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-x", "hip", "--offload-arch=gfx950", SRC, "-x", "none",
+                               "-L", os.path.join(ROOT, "ntt-cuda_amd"), "-lmi355ntt", "-L", os.path.join(ROOT, "oracle"), "-loracle",
+                               "-Wl,-rpath," + os.path.join(ROOT, "ntt-cuda_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-o", EXE])
+    return EXE
+
+
+def test_compat_program_builds(native, oracle):
+    """CPU: the compat headers compile against the C ABI and link (no GPU needed to build)."""
+    assert os.path.exists(build(native, oracle))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2048, 4096, 32768])
+def test_compat_program_matches_schoolbook(native, oracle, gpu, n):
+    exe = build(native, oracle)
+    if n > 8192:
+        pytest.skip("refPolyMul128 is O(n^2): the reference's own check is only practical at small n")
+    r = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "errors = 0" in r.stdout

@@ -1,0 +1,77 @@
+"""CPU: the multi-GPU shard layer (one process per GPU, no data-path collective) with gloo, world size 2.
+The per-rank transform is stood in for by the oracle (tests may use it); what is under test is the partition,
+the scatter/gather plumbing and the timing reduction that bench.py uses at N > 1."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import params as P
+
+
+def test_shard_ranges_cover_and_respect_division():
+    from ntt_cuda_amd.shard import shard_range
+    for num, div, world in [(8192, 4, 8), (1024, 4, 1), (10, 4, 3), (7, 3, 2), (0, 4, 2), (4, 4, 8), (33, 16, 2)]:
+        seen = 0
+        for r in range(world):
+            s, c = shard_range(num, div, r, world)
+            assert s == seen and s % div == 0                      # contiguous, prime index preserved: y % div == (y - s) % div
+            if r < world - 1:
+                assert c % div == 0
+            seen += c
+        assert seen == num
+    with pytest.raises(ValueError):
+        shard_range(8, 0, 0, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, num, n, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (os.path.join(root, "ntt-cuda_amd"), os.path.join(root, "oracle"), here):
+        sys.path.insert(0, p)
+    import oracle_py as oracle
+    from ntt_cuda_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    qs = [P.REF_PARAMS_4096_58BIT[0], P.REF_PARAMS[4096][0], P.EDGE_PRIMES[59][0]]
+    psis = [P.REF_PARAMS_4096_58BIT[1], P.REF_PARAMS[4096][1], P.EDGE_PRIMES[59][1][4096]]
+    prm = oracle.Params(n, qs, psis)
+    full = None
+    if rank == 0:
+        full = torch.from_numpy(oracle.synth_batch(n, num, qs, 1).view(np.int64))
+    local = shard.scatter_batch(full, num, n, len(qs), src=0)
+    start, count = shard.shard_range(num, len(qs), rank, world)
+    assert tuple(local.shape) == (count, n) and start % len(qs) == 0
+    # the shard is transformed with the SAME rule "polynomial y -> prime y % division" because start % division == 0
+    if count:
+        res = oracle.forward_batch(local.numpy().view(np.uint64), prm, division=len(qs)).reshape(count, n)
+        local = torch.from_numpy(res.view(np.int64))
+    dist.barrier()
+    got = shard.gather_batch(local, num, n, len(qs), dst=0)
+    worst = shard.max_over_ranks(0.25 + rank)
+    assert worst == 0.25 + world - 1
+    if rank == 0:
+        want = oracle.forward_batch(full.numpy().view(np.uint64), prm, division=len(qs)).reshape(num, n)
+        np.save(out, np.array([int(np.array_equal(got.numpy().view(np.uint64), want))]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num", [9, 7])
+def test_scatter_transform_gather_world2(tmp_path, num):
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(2, _free_port(), num, 4096, out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1

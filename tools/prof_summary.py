@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         short = name.split("(")[0][-60:]
         acc[short][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
 for k in sorted(acc):
-    if "k_forward" in k or "k_inverse" in k or "k_polymul" in k or "k_pointwise" in k:
+    if any(x in k for x in ("k_forward", "k_inverse", "k_polymul", "k_pointwise")):
         print(k)
         for c in sorted(acc[k]):
             v = acc[k][c]
