@@ -121,6 +121,9 @@ __device__ __forceinline__ TwPair buf_load_tw(BufRsrc r, u32 voff, u32 soff)
 
 // y*w mod q, result congruent and in [0, 4q).  y: any 64-bit value.  wp = floor(w*2^64/q).
 // Quotient estimate from three of the four partial products (error <= 2), remainder as y*w + h*(2^64-q).
+//
+// (gfx950 issues 32-bit multiplies, 64-bit adds and 3-operand adds at half rate; a variant that chains four
+// v_mad_u64_u32 on the high word -- 6 instead of 8 instructions for the remainder -- measured no faster.)
 __device__ __forceinline__ u64 mul_shoup4(u64 y, u64 w, u64 wp, u64 nq)
 {
     u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
@@ -370,24 +373,31 @@ __device__ __forceinline__ void wave_transpose_0_to_5(u64 (&v)[32], u64* slice, 
 
 // Layout 0 <-> global memory with 16-byte accesses.  A wave owns 2048 consecutive coefficients (16 KiB): lane L
 // holds row L (32 words).  Going through the slice in two column halves of 128 B per row lets every global
-// instruction move 8 rows x 128 contiguous bytes.  16-byte slots are XOR-swizzled with the row so both the row
-// accesses (lane = row) and the transposed accesses (8 lanes per row) are bank-conflict free.
+// instruction move 8 rows x 128 contiguous bytes.  Rows are 128 B apart and the eight 16-byte pieces of row R sit
+// at slot piece ^ ((R >> 1) & 7): with that swizzle both the row accesses (lane = row: ds_*_b128 serviced in
+// 16-lane groups {0-3,12-15,20-27}, ...) and the transposed accesses (8 consecutive lanes per row) touch every
+// bank once.  Lane-derived address parts are fenced per call so they are recomputed (2 instructions each)
+// instead of being hoisted out of the polynomial loop and spilled.
+__device__ __forceinline__ unsigned row_swz(unsigned row) { return (row >> 1) & 7u; }
+
 __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, BufRsrc dst, unsigned wave_byte_off, unsigned lane)
 {
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(lane));
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     static_for<2>([&](auto cc) {
         constexpr int ch = decltype(cc)::value;
         static_for<8>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            *reinterpret_cast<ulonglong2*>(base + lane * 128 + ((m ^ sw) << 4)) = make_ulonglong2(v[16 * ch + 2 * m], v[16 * ch + 2 * m + 1]);
+            *reinterpret_cast<ulonglong2*>(base + lane * 128 + ((m ^ row_swz(lane)) << 4)) =
+                make_ulonglong2(v[16 * ch + 2 * m], v[16 * ch + 2 * m + 1]);
         });
         wave_lds_fence();
         static_for<8>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            // row 8k + rr, piece (lane & 7): stored at slot piece ^ (row & 7) = sw ^ rr
-            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + (8 * k + rr) * 128 + ((sw ^ rr) << 4));
+            // row 8k + rr, piece sw
+            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4));
             v4u32 x;
             x.x = lo32(pr.x); x.y = hi32(pr.x); x.z = lo32(pr.y); x.w = hi32(pr.y);
             __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, 0);
@@ -400,6 +410,7 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
 template <int CH>
 __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
 {
+    asm volatile("" : "+v"(lane));
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     v4u32 x[8];
@@ -409,12 +420,12 @@ __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, 
     });
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ rr) << 4)) = x[k];
+        *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4)) = x[k];
     });
     wave_lds_fence();
     static_for<8>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + lane * 128 + ((m ^ sw) << 4));
+        const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + lane * 128 + ((m ^ row_swz(lane)) << 4));
         out[2 * m] = pr.x;
         out[2 * m + 1] = pr.y;
     });
