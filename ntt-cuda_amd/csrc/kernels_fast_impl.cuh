@@ -121,22 +121,33 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64 v[32];
     unsigned y = blockIdx.x;
     load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    [[maybe_unused]] int it = 0;
+    MI355NTT_STAMP_DECL
     for (; y < num; y += gridDim.x) {
         const unsigned idx = prime_base + y % division;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
         u64* poly = a + (size_t)y * G::N;
+        MI355NTT_STAMP2(it, 0);
         ct_round<LOGN, HL, 10, 4>(v, twp, twr, t, p);
+        MI355NTT_STAMP2(it, 1);
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
+        MI355NTT_STAMP2(it, 2);
         exchange<LOGN, 10, 5>(v, lds, t);
+        MI355NTT_STAMP2(it, 3);
         ct_round<LOGN, HL, 5, 4>(v, twp, twr, t, p);
+        MI355NTT_STAMP2(it, 4);
         wave_transpose_5_to_0(v, slice, lane);
         ct_round<LOGN, HL, 0, 4>(v, twp, twr, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q(v[decltype(rc)::value], p), p.q); });
+        MI355NTT_STAMP2(it, 5);
         wave_store_rows(v, slice, make_rsrc(poly, G::N * 8u), wave * 16384u, lane);
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        MI355NTT_STAMP2(it, 6);
+        it++;
     }
+    MI355NTT_STAMP_FLUSH
 }
 
 template <int HL>

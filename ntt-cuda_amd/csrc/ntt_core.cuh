@@ -37,17 +37,33 @@ __device__ __forceinline__ void static_for(F&& f)
 // go to a buffer of their own and never feed an output.
 #ifdef MI355NTT_STAMPS
 __device__ unsigned long long* g_stamp_buf;
-__device__ __forceinline__ void stamp(int slot)
+// Segment timing with scalar accumulators only (no VGPRs, no memory traffic inside the loop): each wave adds the
+// shader-clock time between consecutive marks into 8 SGPR sums and stores them once after the loop.
+struct StampAcc {
+    unsigned long long prev, sum[8];
+};
+__device__ __forceinline__ unsigned long long stamp_now()
 {
-    __builtin_amdgcn_sched_barrier(0);
     unsigned long long tm;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if ((threadIdx.x & 63) == 0) g_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + slot] = tm;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+    return tm;
 }
-#define MI355NTT_STAMP(slot) stamp(slot)
+__device__ __forceinline__ unsigned long long stamp_real()
+{
+    unsigned long long tm;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+    return tm;
+}
+#define MI355NTT_STAMP_DECL StampAcc sacc; sacc.prev = stamp_now(); for (int k_ = 0; k_ < 8; k_++) sacc.sum[k_] = 0; unsigned long long real0_ = stamp_real(), clk0_ = sacc.prev;
+#define MI355NTT_STAMP2(it, slot) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = stamp_now(); sacc.sum[slot] += n_ - sacc.prev; sacc.prev = n_; __builtin_amdgcn_sched_barrier(0); }
+#define MI355NTT_STAMP_FLUSH { unsigned long long real1_ = stamp_real(), clk1_ = stamp_now(); sacc.sum[7] = ((clk1_ - clk0_) << 24) / (real1_ - real0_ + 1); /* shader cycles per 100 MHz tick, x 2^24 */ \
+    if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 8; k_++) g_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k_] = sacc.sum[k_]; } }
+#define MI355NTT_STAMP(slot)
 #else
 #define MI355NTT_STAMP(slot)
+#define MI355NTT_STAMP2(it, slot)
+#define MI355NTT_STAMP_DECL
+#define MI355NTT_STAMP_FLUSH
 #endif
 
 // Per-prime constants, read with scalar loads (replaces __constant__ q_cons/mu_cons/q_bit_cons).

@@ -293,6 +293,34 @@ def test_full_size_properties(native, oracle, gpu, num):
     ctx.close()
 
 
+@pytest.mark.parametrize("num", [257, 777])
+def test_persistent_loop_ragged_counts(native, oracle, gpu, num):
+    """n = 2^15 kernels are persistent (grid = min(num, #CUs), each workgroup walks y, y + grid, ...): batch sizes that
+    are not multiples of the grid or of the prime count must still transform every polynomial exactly once."""
+    import torch
+    n, qs, psis = 32768, P.Q60, P.PSI60
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = native.to_device(oracle.synth_batch(n, num, qs, 4242))
+    b = native.to_device(oracle.synth_batch(n, num, qs, 9000))
+    a0 = a.clone()
+    ctx.forward_batch(a, num)
+    A = a.clone()
+    sample = [0, 1, 255, 256, num - 2, num - 1]
+    for y in sample:
+        assert np.array_equal(native.to_host(A[y].contiguous()), oracle.forward(native.to_host(a0[y].contiguous()), prm, y % 4)), y
+    ctx.inverse_batch(a, num)
+    assert torch.equal(a, a0)
+    ctx.forward_batch(b, num)
+    c = A.clone()
+    ctx.pointwise_mul(c, A, b, num)
+    ctx.inverse_batch(c, num)
+    f = a0.clone()
+    ctx.polymul_batch(f, b, num)
+    assert torch.equal(f, c)
+    ctx.close()
+
+
 def test_streams_are_respected(native, oracle, gpu):
     """All entry points are asynchronous on the caller's stream (the reference's batch launchers use stream 0)."""
     import torch

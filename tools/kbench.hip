@@ -43,7 +43,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dp, &d, sizeof(d), hipMemcpyHostToDevice));
 #ifdef MI355NTT_STAMPS
     unsigned long long* dstamp;
-    CK(hipMalloc(&dstamp, (size_t)num * 16 * 16 * 8));
+    CK(hipMalloc(&dstamp, (size_t)256 * 16 * 8 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dstamp, sizeof(dstamp)));
 #endif
     hipEvent_t e0, e1;
@@ -63,25 +63,29 @@ int main(int argc, char** argv)
         }
         std::sort(ts.begin(), ts.end());
 #ifdef MI355NTT_STAMPS
-        {
-            std::vector<unsigned long long> st((size_t)num * 256);
+        if (which == 0) {
+            // forward15: per-wave sums over all iterations of the time between marks:
+            // slot 0: (store+issue of previous iteration ->) loop top, 1: R1 incl. load wait, 2: wait at sync, 3: exchange,
+            // 4: R2, 5: T5->0 + R3 + canon, 6: row store + issue next loads
+            unsigned nb = num < 256 ? num : 256;
+            std::vector<unsigned long long> st((size_t)nb * 16 * 8);
             CK(hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost));
-            // forward slots: 15 start,0 load,1 R1,2 E1,3 R2,4 E2,5 R3,6 canon,7 E3,8 store ; inverse: 15,0 load,1 E0,3 R1,4 E1,5 R2,6 E2,7 R3,8 canon,9 store
-            const int seqf[] = {15, 0, 1, 2, 3, 4, 5, 6, 7, 8};
-            const char* nmf[] = {"load", "R1", "E1", "R2", "E2", "R3", "canon", "E3", "store"};
-            const int seqi[] = {15, 0, 1, 3, 4, 5, 6, 7, 8, 9};
-            const char* nmi[] = {"load", "E0", "R1", "E1", "R2", "E2", "R3+canon", "-", "store"};
-            const int* seq = which ? seqi : seqf;
-            const char** nm = which ? nmi : nmf;
-            double tot = 0;
-            for (int ph = 0; ph < 9; ph++) {
-                double acc = 0;
-                for (size_t w = 0; w < (size_t)num * 16; w++) acc += (double)(st[w * 16 + seq[ph + 1]] - st[w * 16 + seq[ph]]);
-                acc /= (double)num * 16;
-                tot += acc;
-                printf("    %-9s %9.0f cycles\n", nm[ph], acc);
+            const char* nm[] = {"(loop top)", "R1 incl. load wait", "wait at sync", "exchange 10->5", "R2", "T5->0 + R3 + canon", "row store + issue next loads", "-"};
+            double iters = (double)num / nb, tot = 0;
+            for (int ph = 0; ph < 7; ph++) {
+                double acc = 0, mn = 1e18, mx = 0;
+                for (size_t w = 0; w < (size_t)nb * 16; w++) { double d = (double)st[w * 8 + ph] / iters; acc += d; mn = d < mn ? d : mn; mx = d > mx ? d : mx; }
+                printf("    %-30s %9.0f cycles/poly  [wave min %8.0f .. max %8.0f]\n", nm[ph], acc / (nb * 16.0), mn, mx);
+                tot += acc / (nb * 16.0);
             }
-            printf("    total     %9.0f cycles per wave lifetime (stamped build)\n", tot);
+            printf("    total                          %9.0f cycles per polynomial per wave\n", tot);
+            { double c = 0; for (size_t w = 0; w < (size_t)nb * 16; w++) c += (double)st[w * 8 + 7] / 16777216.0; printf("    in-kernel clock (memtime/memrealtime x 100 MHz): %.3f GHz\n", c / (nb * 16.0) * 0.1); }
+            printf("    WG0 per wave (cycles/poly): R1+wait | sync | xchg | R2 | R3 | store\n");
+            for (int w = 0; w < 16; w++) {
+                printf("     w%02d", w);
+                for (int ph = 1; ph < 7; ph++) printf(" %8.0f", (double)st[w * 8 + ph] / iters);
+                printf("\n");
+            }
         }
 #endif
         printf("%s  num=%u  median %.4f ms  min %.4f ms  => %.3f M transforms/s  (%.1f%% of 15.26M)\n", which ? "inverse" : "forward", num,
