@@ -69,34 +69,50 @@ def cpu_baseline(n, qs, psis):
     except Exception:
         lib = oracle.lib()
     prm = oracle.Params(n, qs, psis)
-    num = 64 * max(1, cores // 8)
-    num = max(num, 2 * cores)
-    num -= num % len(qs)
-    a = oracle.synth_batch(n, num, qs, 1)
-    u64p, u32p = oracle.u64p, oracle.u32p
     import ctypes
+    u64p, u32p = oracle.u64p, oracle.u32p
 
-    def call(name, arr, tabs):
-        f = getattr(lib, name)
-        f.restype = None
-        f.argtypes = [u64p, ctypes.c_uint, u64p, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, ctypes.c_int]
-        f(arr.ctypes.data_as(u64p), n, tabs.ctypes.data_as(u64p), num, len(qs), prm.q.ctypes.data_as(u64p),
-          prm.mu.ctypes.data_as(u64p), prm.k.ctypes.data_as(u32p), cores)
+    def run(num, threads, min_wall):
+        a = oracle.synth_batch(n, num, qs, 1)
+        work = a.copy()
 
-    work = a.copy()
-    call("orc_forward_batch", work, prm.psi_tabs)        # warm-up + correctness of the round trip
-    call("orc_inverse_batch", work, prm.psiinv_tabs)
-    assert np.array_equal(work, a)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        call("orc_forward_batch", work, prm.psi_tabs)
-        call("orc_inverse_batch", work, prm.psiinv_tabs)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= 3.0:
-            break
-    return {"value": num * reps / el, "unit": "fwd+inv NTT pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d polys (n=%d, %d primes) x %d passes, OpenMP over polynomials, %.1f s wall" % (num, n, len(qs), reps, el)}
+        def call(name, tabs):
+            f = getattr(lib, name)
+            f.restype = None
+            f.argtypes = [u64p, ctypes.c_uint, u64p, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, ctypes.c_int]
+            f(work.ctypes.data_as(u64p), n, tabs.ctypes.data_as(u64p), num, len(qs), prm.q.ctypes.data_as(u64p),
+              prm.mu.ctypes.data_as(u64p), prm.k.ctypes.data_as(u32p), threads)
+
+        call("orc_forward_batch", prm.psi_tabs)        # warm-up + correctness of the round trip
+        call("orc_inverse_batch", prm.psiinv_tabs)
+        assert np.array_equal(work, a)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            call("orc_forward_batch", prm.psi_tabs)
+            call("orc_inverse_batch", prm.psiinv_tabs)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= min_wall:
+                break
+        return num * reps / el, reps, el
+
+    # single thread first (the reference-style scalar rate), then OpenMP over polynomials at a few thread counts;
+    # report the best aggregate and the threads it used
+    single, _, _ = run(8, 1, 1.0)
+    best = (single, 1, 8, 0, 0.0)
+    tried = {1: single}
+    for th in sorted({max(1, cores // 4), max(1, cores // 2), cores}):
+        if th == 1:
+            continue
+        num = 4 * th - (4 * th) % len(qs)
+        rate, reps, el = run(num, th, 2.0)
+        tried[th] = rate
+        if rate > best[0]:
+            best = (rate, th, num, reps, el)
+    return {"value": best[0], "unit": "fwd+inv NTT pairs/s", "cores": best[1], "kind": "port",
+            "sample": "%d polys (n=%d, %d primes) x %d passes, OpenMP over polynomials, %.1f s wall; host has %d logical CPUs; "
+                      "rates by thread count: %s" % (best[2], n, len(qs), best[3], best[4], cores,
+                                                     ", ".join("%d: %.0f" % (k, v) for k, v in sorted(tried.items())))}
 
 
 def main():

@@ -103,6 +103,14 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     }
 }
 
+// Wave priorities per phase (s_setprio; priority outranks age in the SIMD's issue arbitration).
+#ifndef MI355NTT_PRIO_R1
+#define MI355NTT_PRIO_R1 0
+#define MI355NTT_PRIO_R2 0
+#define MI355NTT_PRIO_R3 0
+#endif
+#define MI355NTT_SETPRIO(x) do { if ((MI355NTT_PRIO_R1 | MI355NTT_PRIO_R2 | MI355NTT_PRIO_R3) != 0) __builtin_amdgcn_s_setprio(x); } while (0)
+
 // ================================================================================================
 // n = 2^15: one workgroup-wide exchange per transform, everything else wave-local (ntt_core.cuh).
 // forward : load(layout 10) R1 | sync, exchange 10->5 | R2 | wave transpose 5->0 | R3 | canon | wave-local row store
@@ -130,15 +138,18 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
         u64* poly = a + (size_t)y * G::N;
         MI355NTT_STAMP2(it, 0);
+        MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
         ct_round<LOGN, HL, 10, 4>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 1);
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
         MI355NTT_STAMP2(it, 2);
         exchange<LOGN, 10, 5>(v, lds, t);
         MI355NTT_STAMP2(it, 3);
+        MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
         ct_round<LOGN, HL, 5, 4>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 4);
         wave_transpose_5_to_0(v, slice, lane);
+        MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
         ct_round<LOGN, HL, 0, 4>(v, twp, twr, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMP2(it, 5);
