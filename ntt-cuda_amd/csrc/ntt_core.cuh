@@ -231,7 +231,10 @@ struct Geo {
     static constexpr int T = N / 32;                  // threads per polynomial
     static constexpr int B0 = LOGN - 5;               // coalesced layout: i = (r << B0) | t
     static constexpr int NR = (LOGN + 4) / 5;         // rounds
-    static constexpr bool TWO_PHASE = (N * 8 > 131072);   // LDS holds half a 2^15 polynomial at a time
+#ifndef MI355NTT_TWO_PHASE_MIN_LOGN
+#define MI355NTT_TWO_PHASE_MIN_LOGN 13   // half-size image from n = 2^13 up: 2-4 workgroups share a CU (n = 2^15 needs it to fit at all)
+#endif
+    static constexpr bool TWO_PHASE = (LOGN >= MI355NTT_TWO_PHASE_MIN_LOGN);   // LDS image holds half a polynomial at a time
     static constexpr int PB = LOGN - 1;               // index bit that selects the phase
     static constexpr int ROWS = (TWO_PHASE ? N / 2 : N) / 32;
     static constexpr int LDS_WORDS = (LOGN == 15) ? 16 * 1152 : ROWS * 34;   // image (32 + 2 pad words per row); n = 2^15: 16 wave slices of 9216 B
