@@ -178,12 +178,17 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const unsigned t0 = threadIdx.x;
+    const unsigned lane = t0 & 63u, wave = t0 >> 6;
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
     wave_load_rows(v, slice, make_rsrc(a + (size_t)y * G::N, G::N * 8u), wave * 16384u, lane);
     for (; y < num; y += gridDim.x) {
+        unsigned t = t0;
+        asm volatile("" : "+v"(t));      // thread-derived offsets are recomputed per polynomial, not kept live across the loop
+        const unsigned lane = t & 63u, wave = t >> 6;
+        u64* slice = lds + wave * WAVE_SLICE_WORDS;
         const unsigned idx = prime_base + y % division;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;

@@ -538,7 +538,10 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
 {
     constexpr InvPolicy<LOGN, HL> POL{};
     constexpr bool EX = Lazy<HL>::EXACT;
-    constexpr int GROUP = SCHED_GROUP, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
+#ifndef MI355NTT_GS_GROUP_B0
+#define MI355NTT_GS_GROUP_B0 SCHED_GROUP
+#endif
+    constexpr int GROUP = (B == 0) ? MI355NTT_GS_GROUP_B0 : SCHED_GROUP, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
     constexpr bool VEC = (B != Geo<LOGN>::B0);
     const unsigned thi = t >> B;
     TwPair Wc[GROUP], Wn[GROUP];
@@ -568,6 +571,9 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
                 v[r0] = S;
                 v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
             }
+#ifdef MI355NTT_INNER_FENCE
+            if constexpr (VEC && ((k + 1) % MI355NTT_INNER_FENCE) == 0 && k + 1 < GROUP) __builtin_amdgcn_sched_barrier(0);
+#endif
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         if constexpr (g + 1 < NG) static_for<GROUP>([&](auto kc) { Wc[decltype(kc)::value] = Wn[decltype(kc)::value]; });
