@@ -1,0 +1,47 @@
+// bfv_launch.hpp -- the NTT sections of the reference's BFV drivers as host launch sequences on a context.
+//
+// In ozgunozerk/NTT-Cuda the drivers keygen_rns / encryption_rns / decryption_rns are pure kernel-launch sequences;
+// their NTT hot path is the triple forwardNTT_batch -> barrett_batch* -> inverseNTT_batch on the legacy default
+// stream.  These functions are those call sites (same buffer layouts, same num/division arguments), issued on the
+// caller's stream through the throughput kernels of libmi355ntt.  Everything around them in the drivers
+// (samplers, poly_add_*, divide_and_round_*, base conversion) is outside the NTT path and stays with the caller.
+#pragma once
+#include "../../include/mi355ntt.h"
+
+namespace mi355 {
+
+// bfv_keygen.cuh:129-133 -- secret_key: [r][n] ternary sample (in place -> NTT domain);
+// public_key: [2][r][n], pk1 (second half) uniform; on return pk0 = INTT(pk1 (.) NTT(sk)) in the coefficient domain.
+inline int keygen_ntt_a(const mi355ntt_ctx* ctx, unsigned long long* secret_key, unsigned long long* public_key, unsigned n,
+                        unsigned q_amount, mi355ntt_stream stream)
+{
+    int rc = mi355ntt_forward_batch(ctx, secret_key, q_amount, q_amount, stream);                       // :129
+    if (rc) return rc;
+    rc = mi355ntt_pointwise_mul(ctx, public_key, public_key + (size_t)q_amount * n, secret_key, q_amount, q_amount, stream);  // :131-132
+    if (rc) return rc;
+    return mi355ntt_inverse_batch(ctx, public_key, q_amount, q_amount, stream);                          // :133
+}
+
+// bfv_keygen.cuh:145 -- after poly_add_negate_xq: pk0 back to the NTT domain
+inline int keygen_ntt_b(const mi355ntt_ctx* ctx, unsigned long long* public_key, unsigned q_amount, mi355ntt_stream stream)
+{
+    return mi355ntt_forward_batch(ctx, public_key, q_amount, q_amount, stream);
+}
+
+// bfv_encryption.cuh:268-271 -- c: [2][r][n] (u twice), public_key: [2][r][n] in the NTT domain:
+// c[j] = INTT(NTT(c[j]) (.) pk[j]) for all 2r polynomials, one fused launch
+inline int encryption_ntt(const mi355ntt_ctx* ctx, unsigned long long* c, const unsigned long long* public_key, unsigned q_amount,
+                          mi355ntt_stream stream)
+{
+    return mi355ntt_polymul_batch(ctx, c, public_key, 2 * q_amount, q_amount, stream);
+}
+
+// bfv_decryption.cuh:98-101 -- q_amount = r (the special prime is already dropped, the context still holds r + 1 primes);
+// c: [2][r + 1][n]; c1 = c + (r + 1) n; secret_key: [r][n] in the NTT domain: c1[i] = INTT(NTT(c1[i]) (.) sk[i]), i < r
+inline int decryption_ntt(const mi355ntt_ctx* ctx, unsigned long long* c, const unsigned long long* secret_key, unsigned n,
+                          unsigned q_amount, mi355ntt_stream stream)
+{
+    return mi355ntt_polymul_batch(ctx, c + (size_t)(q_amount + 1) * n, secret_key, q_amount, q_amount + 1, stream);
+}
+
+}  // namespace mi355

@@ -9,6 +9,7 @@
 
 #include "../../ntt-cuda_amd/compat/ntt_60bit.hpp"
 #include "../../ntt-cuda_amd/compat/poly_arithmetic.hpp"
+#include "../../ntt-cuda_amd/compat/bfv_launch.hpp"   // compile check of the BFV launch layer
 #include "../../oracle/ntt_oracle.h"
 
 using namespace mi355;
