@@ -314,13 +314,14 @@ inline unsigned persistent_grid(unsigned num)
     const unsigned by_lds = 163840u / (G::LDS_WORDS * 8u);
     unsigned per_cu = by_waves < by_lds ? by_waves : by_lds;
     if (per_cu < 1) per_cu = 1;
-    int cus = 256;
+    static thread_local int cached_dev = -1, cached_cus = 256;                      // CU count of the current device
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) {
+    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
         int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        cached_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        cached_dev = dev;
     }
-    const unsigned cap = (unsigned)cus * per_cu;
+    const unsigned cap = (unsigned)cached_cus * per_cu;
     return num < cap ? num : cap;
 }
 
