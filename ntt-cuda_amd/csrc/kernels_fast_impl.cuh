@@ -334,11 +334,11 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
         if (hl >= 6) k_forward15<6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else if (hl >= 4) k_forward15<4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_forward15<2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        return hipGetLastError();
+    } else {
+        if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     }
-    if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-    else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-    else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     return hipGetLastError();
 }
 
@@ -351,11 +351,11 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
         if (hl >= 6) k_inverse15<6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else if (hl >= 4) k_inverse15<4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_inverse15<2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        return hipGetLastError();
+    } else {
+        if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     }
-    if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-    else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-    else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     return hipGetLastError();
 }
 
@@ -368,12 +368,12 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
         if (hl >= 6) k_polymul15<6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
         else if (hl >= 4) k_polymul15<4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
         else k_polymul15<2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-        return hipGetLastError();
+    } else {
+        dim3 g(num), b(Geo<LOGN>::T);
+        if (hl >= 6) k_polymul<LOGN, 6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+        else if (hl >= 4) k_polymul<LOGN, 4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+        else k_polymul<LOGN, 2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
     }
-    dim3 g(num), b(Geo<LOGN>::T);
-    if (hl >= 6) k_polymul<LOGN, 6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-    else if (hl >= 4) k_polymul<LOGN, 4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-    else k_polymul<LOGN, 2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
     return hipGetLastError();
 }
 
