@@ -36,7 +36,7 @@ struct FastTables {
     u64* d_fwd = nullptr;      // psi^bitrev(i)
     u64* d_inv = nullptr;      // psi^-bitrev(i)
     void* d_primes = nullptr;  // [P] PrimeDev records (ntt_core.cuh)
-    int hl = 6;                // headroom class of the context: min over primes of (64 - bit length), capped at 6
+    int hl = 6;                // bits 0-3: headroom class = min over primes of (64 - bit length), capped at 6; bit 4: all primes near 2^k
     const u64* d_psi = nullptr;     // reference-format tables owned by the context (fallback path)
     const u64* d_psiinv = nullptr;
 };

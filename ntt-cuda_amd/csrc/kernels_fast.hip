@@ -62,6 +62,7 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
     t->d_psi = d_psi;
     t->d_psiinv = d_psiinv;
     t->hl = 6;
+    bool all_near = true;
     std::vector<PrimeDev> pd(num_primes);
     for (unsigned i = 0; i < num_primes; i++) {
         const PrimeParams& pp = prime[i];
@@ -70,6 +71,7 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         t->mods.mu[i] = pp.mu;
         t->mods.k[i] = pp.k;
         int hl = 64 - (int)pp.k;
+        if (hl > 6) hl = 6;
         if (hl < t->hl) t->hl = hl;
         PrimeDev& d = pd[i];
         d.q = pp.q;
@@ -85,7 +87,16 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         d.red_sh1 = pp.k - 1 - g;
         d.red_sh2 = g;
         d.red_c = (u32)((((u128)1) << (31 + pp.k)) / pp.q);
+        // near-2^k shape: q = 2^k - delta, k > 32, delta < 2^24 and 2^(64-k) * delta + 2 * delta < 2^k (reduce_2q_near)
+        const u128 dl = (((u128)1) << pp.k) - pp.q;
+        const bool near_ok = pp.k > 32 && dl < ((u128)1 << 24) && ((dl << (64 - pp.k)) + 2 * dl) < (((u128)1) << pp.k);
+        d.delta = near_ok ? (u32)dl : 0;
+        d.near_sh = pp.k > 32 ? pp.k - 32 : 0;
+        d.near_mask = pp.k > 32 ? (u32)((1ull << (pp.k - 32)) - 1) : 0;
+        d.pad_ = 0;
+        if (!near_ok) all_near = false;
     }
+    if (all_near) t->hl |= 16;
     const size_t words = (size_t)num_primes * n;
     // device layout: stage blocks transposed per round (ntt_core.cuh, tw_dev_index); entry 0 is never read
     std::vector<TwPair> hf(words), hi(words);

@@ -125,7 +125,7 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 // forward : load(layout 10) R1 | sync, exchange 10->5 | R2 | wave transpose 5->0 | R3 | canon | wave-local row store
 // inverse : wave-local row load (layout 0) | R1' | wave transpose 0->5 | R2' | sync, exchange 5->10 | R3' | canon | store
 // ================================================================================================
-template <int HL>
+template <int HL, bool NEAR>
 __global__ void __launch_bounds__(1024, 4)
 k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
             unsigned prime_base, unsigned num)
@@ -148,19 +148,19 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         u64* poly = a + (size_t)y * G::N;
         MI355NTT_STAMP2(it, 0);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
-        ct_round<LOGN, HL, 10, 4>(v, twp, twr, t, p);
+        ct_round<LOGN, HL, 10, 4, NEAR>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 1);
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
         MI355NTT_STAMP2(it, 2);
         exchange<LOGN, 10, 5>(v, lds, t);
         MI355NTT_STAMP2(it, 3);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
-        ct_round<LOGN, HL, 5, 4>(v, twp, twr, t, p);
+        ct_round<LOGN, HL, 5, 4, NEAR>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 4);
         wave_transpose_5_to_0(v, slice, lane);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
-        ct_round<LOGN, HL, 0, 4>(v, twp, twr, t, p);
-        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q(v[decltype(rc)::value], p), p.q); });
+        ct_round<LOGN, HL, 0, 4, NEAR>(v, twp, twr, t, p);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMP2(it, 5);
         wave_store_rows(v, slice, make_rsrc(poly, G::N * 8u), wave * 16384u, lane);
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
@@ -170,7 +170,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     MI355NTT_STAMP_FLUSH
 }
 
-template <int HL>
+template <int HL, bool NEAR>
 __global__ void __launch_bounds__(1024, 4)
 k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
             unsigned prime_base, unsigned num)
@@ -195,14 +195,14 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
         u64* poly = a + (size_t)y * G::N;
         MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
-        gs_round<LOGN, HL, 0, 0>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p);
         wave_transpose_0_to_5(v, slice, lane);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-        gs_round<LOGN, HL, 5, 0>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 5, 0, NEAR>(v, twp, twr, t, p);
         __syncthreads();                                  // private slices are idle from here on
         exchange<LOGN, 5, 10>(v, lds, t);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, twr, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num)
@@ -210,7 +210,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     }
 }
 
-template <int HL>
+template <int HL, bool NEAR>
 __global__ void __launch_bounds__(1024, 4)
 k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
             const PrimeDev* __restrict__ primes, unsigned division, unsigned num)
@@ -233,37 +233,37 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         const BufRsrc brs = make_rsrc(bhat + (size_t)y * G::N, G::N * 8u);
         // ---- forward ----
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
-        ct_round<LOGN, HL, 10, 4>(v, tf, tfr, t, p);
+        ct_round<LOGN, HL, 10, 4, NEAR>(v, tf, tfr, t, p);
         __syncthreads();
         exchange<LOGN, 10, 5>(v, lds, t);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
-        ct_round<LOGN, HL, 5, 4>(v, tf, tfr, t, p);
+        ct_round<LOGN, HL, 5, 4, NEAR>(v, tf, tfr, t, p);
         wave_transpose_5_to_0(v, slice, lane);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
-        ct_round<LOGN, HL, 0, 4>(v, tf, tfr, t, p);
+        ct_round<LOGN, HL, 0, 4, NEAR>(v, tf, tfr, t, p);
         // ---- pointwise product with bhat, streamed 16 words per lane at a time (layout 0 on both sides) ----
         {
             u64 bb[16];
             wave_load_rows_half<0>(bb, slice, brs, wave * 16384u, lane);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                v[r] = barrett_mul(canon_2q(reduce_2q(v[r], p), p.q), bb[r], p.q, p.mu, p.k);   // poly_arithmetic.cuh:36-66
+                v[r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[r], p), p.q), bb[r], p.q, p.mu, p.k);   // poly_arithmetic.cuh:36-66
             });
             wave_load_rows_half<1>(bb, slice, brs, wave * 16384u, lane);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                v[16 + r] = barrett_mul(canon_2q(reduce_2q(v[16 + r], p), p.q), bb[r], p.q, p.mu, p.k);
+                v[16 + r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[16 + r], p), p.q), bb[r], p.q, p.mu, p.k);
             });
         }
         // ---- inverse ----
-        gs_round<LOGN, HL, 0, 0>(v, ti, tir, t, p);
+        gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, t, p);
         wave_transpose_0_to_5(v, slice, lane);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-        gs_round<LOGN, HL, 5, 0>(v, ti, tir, t, p);
+        gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, t, p);
         __syncthreads();
         exchange<LOGN, 5, 10>(v, lds, t);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0>(v, ti, tir, t, p);
+        gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
@@ -331,10 +331,19 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
     if constexpr (LOGN == 15) {
-        if (hl >= 6) k_forward15<6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else if (hl >= 4) k_forward15<4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else k_forward15<2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
+        const int h = hl & 15;
+        if (near) {
+            if (h >= 6) k_forward15<6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (h >= 4) k_forward15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_forward15<2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        } else {
+            if (h >= 6) k_forward15<6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (h >= 4) k_forward15<4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_forward15<2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        }
     } else {
+        hl &= 15;
         if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -348,10 +357,19 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
     if constexpr (LOGN == 15) {
-        if (hl >= 6) k_inverse15<6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else if (hl >= 4) k_inverse15<4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else k_inverse15<2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
+        const int h = hl & 15;
+        if (near) {
+            if (h >= 6) k_inverse15<6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (h >= 4) k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_inverse15<2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        } else {
+            if (h >= 6) k_inverse15<6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (h >= 4) k_inverse15<4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_inverse15<2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        }
     } else {
+        hl &= 15;
         if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -365,10 +383,19 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
 {
     if constexpr (LOGN == 15) {
         dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
-        if (hl >= 6) k_polymul15<6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-        else if (hl >= 4) k_polymul15<4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-        else k_polymul15<2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
+        const int h = hl & 15;
+        if (near) {
+            if (h >= 6) k_polymul15<6, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+            else if (h >= 4) k_polymul15<4, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+            else k_polymul15<2, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        } else {
+            if (h >= 6) k_polymul15<6, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+            else if (h >= 4) k_polymul15<4, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+            else k_polymul15<2, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        }
     } else {
+        hl &= 15;
         dim3 g(num), b(Geo<LOGN>::T);
         if (hl >= 6) k_polymul<LOGN, 6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
         else if (hl >= 4) k_polymul<LOGN, 4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);

@@ -76,6 +76,10 @@ struct PrimeDev {
     u32 red_sh1;      // k - 1 - g
     u32 red_sh2;      // g = min(16, k-1)
     u32 k;            // bit length
+    u32 delta;        // 2^k - q when that is small ("near-2^k" prime, the shape of every SEAL-style modulus), else 0
+    u32 near_sh;      // k - 32
+    u32 near_mask;    // 2^(k-32) - 1
+    u32 pad_;
 };
 
 struct TwPair {       // {w, floor(w * 2^64 / q)}
@@ -168,6 +172,22 @@ __device__ __forceinline__ u64 reduce_2q(u64 x, const PrimeDev& p)
     u32 t = (u32)(x >> p.red_sh1);
     u32 e = __umulhi(t, p.red_c) >> p.red_sh2;
     return x + (u64)e * p.nq;      // e < 2^32: low 64 bits of e*nq added = x - e*q
+}
+
+// Same contract for primes q = 2^k - delta with small delta (k > 32, 2^(64-k) * delta + 2 delta < 2^k, checked on
+// the host): with e = x >> k,  x - e*2^k = x mod 2^k  and  e*2^k = e*q + e*delta, so  x = (x mod 2^k) + e*delta (mod q).
+// Three instructions (shift, and, multiply-add) instead of seven.
+__device__ __forceinline__ u64 reduce_2q_near(u64 x, const PrimeDev& p)
+{
+    const u32 e = hi32(x) >> p.near_sh;
+    const u64 xm = ((u64)(hi32(x) & p.near_mask) << 32) | lo32(x);
+    return mad32(e, p.delta, xm);
+}
+template <bool NEAR>
+__device__ __forceinline__ u64 reduce_2q_sel(u64 x, const PrimeDev& p)
+{
+    if constexpr (NEAR) return reduce_2q_near(x, p);
+    else return reduce_2q(x, p);
 }
 
 // [0, 2q) -> [0, q)
@@ -499,7 +519,7 @@ __device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* 
 }
 
 // Forward (CT) stages on register bits JHI..0 of a layout with register field at bit B.
-template <int LOGN, int HL, int B, int JHI>
+template <int LOGN, int HL, int B, int JHI, bool NEAR = false>
 __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
     constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
@@ -522,7 +542,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
             constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
             constexpr int r1 = r0 | (1 << j);
             u64 U = v[r0];
-            if constexpr (red) U = reduce_2q(U, p);
+            if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
             const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
             v[r0] = U + Tm;
             v[r1] = U + cq - Tm;
@@ -533,7 +553,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
 }
 
 // Inverse (GS) stages on register bits JLO..4 of a layout with register field at bit B.
-template <int LOGN, int HL, int B, int JLO>
+template <int LOGN, int HL, int B, int JLO, bool NEAR = false>
 __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
     constexpr InvPolicy<LOGN, HL> POL{};
@@ -567,7 +587,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
                 v[r0] = mul_shoup<EX>(S, p.ninv, p.ninv_p, p.nq);
                 v[r1] = mul_shoup<EX>(D, p.w1n, p.w1n_p, p.nq);
             } else {
-                if constexpr (red) S = reduce_2q(S, p);
+                if constexpr (red) S = reduce_2q_sel<NEAR>(S, p);
                 v[r0] = S;
                 v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
             }

@@ -31,6 +31,8 @@ int main(int argc, char** argv)
     PrimeDev d{};
     d.q = q; d.nq = 0ULL - q; d.ninv = pp.ninv; d.ninv_p = shoup(pp.ninv, q); d.w1n = 12345; d.w1n_p = shoup(12345, q);
     d.mu = pp.mu; d.k = pp.k; d.red_sh1 = pp.k - 17; d.red_sh2 = 16; d.red_c = (u32)((((u128)1) << (31 + pp.k)) / q);
+    d.delta = (u32)((1ull << pp.k) - q); d.near_sh = pp.k - 32; d.near_mask = (u32)((1ull << (pp.k - 32)) - 1);
+    const int HLSEL = argc > 3 ? atoi(argv[3]) : 4;
     u64* a; TwPair* dtw; PrimeDev* dp;
     CK(hipMalloc(&a, (size_t)num * n * 8));
     CK(hipMalloc(&dtw, n * sizeof(TwPair)));
@@ -50,13 +52,13 @@ int main(int argc, char** argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int which = 0; which < 2; which++) {
         for (int i = 0; i < 3; i++) {
-            if (which == 0) launch_fwd<LOGN>(4, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(4, a, dtw, dp, num, 1, 0, 0);
+            if (which == 0) launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
         }
         CK(hipDeviceSynchronize());
         std::vector<float> ts;
         for (int i = 0; i < reps; i++) {
             CK(hipEventRecord(e0));
-            if (which == 0) launch_fwd<LOGN>(4, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(4, a, dtw, dp, num, 1, 0, 0);
+            if (which == 0) launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
