@@ -220,18 +220,25 @@ def main():
         torch.cuda.synchronize()
         mul_ms = e0.elapsed_time(e1) / 20
         one = synth(torch, 1, n, Q60[:1], dev, seed=9)
-        for _ in range(3):
-            ctx.forward(one, 0)
-            ctx.inverse(one, 0)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(200):
-            ctx.forward(one, 0)
-            ctx.inverse(one, 0)
-        e1.record()
-        torch.cuda.synchronize()
+
+        def lat(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(200):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 200 * 1e3
+
+        pair_us = lat(lambda: (ctx.forward(one, 0), ctx.inverse(one, 0)))
+        fwd_us = lat(lambda: ctx.forward(one, 0))
+        inv_us = lat(lambda: ctx.inverse(one, 0))
         out["extras"] = {"config2_fused_polymul_batch256_per_s": 256 / (mul_ms * 1e-3), "config2_fused_polymul_ms": mul_ms,
-                         "config1_batch1_fwd_inv_pair_us": e0.elapsed_time(e1) / 200 * 1e3}
+                         "config1_batch1_fwd_inv_pair_us": pair_us, "config1_batch1_forward_us": fwd_us,
+                         "config1_batch1_inverse_us": inv_us,
+                         "reference_published_v100_us": {"forward": 39, "inverse": 23, "source": "Article.pdf p25 Table 6 (55-bit q)"}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, Q60, PSI60)
     elif rank == 0:

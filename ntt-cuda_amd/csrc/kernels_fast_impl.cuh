@@ -270,6 +270,105 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     }
 }
 
+// ================================================================================================
+// n = 2^15, SMALL batches (latency path): the same rounds cut into two launches of one-wave workgroups so that a
+// single polynomial spreads over 16 CUs instead of one (the reference's own headline numbers are batch-1
+// latencies: 39 us NTT / 23 us INTT on V100, Article.pdf p25).  The workgroup-wide exchange is replaced by the
+// round trip through memory between the two launches: "cols" does the round on index bits 14..10 for 64 columns,
+// "rows" does the ten stages that stay inside 2048 consecutive coefficients, entirely wave-local.  Values travel
+// between the launches in lazy form [0, B*q); the compile-time bound tracking continues across them.
+// ================================================================================================
+template <int HL, bool NEAR>
+__global__ void __launch_bounds__(64, 1)
+k_fwd15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+             unsigned prime_base)
+{
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    const unsigned y = blockIdx.x >> 4, t = ((blockIdx.x & 15u) << 6) | threadIdx.x;
+    const unsigned idx = prime_base + y % division;
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * G::N;
+    u64* poly = a + (size_t)y * G::N;
+    u64 v[32];
+    load_coalesced<LOGN>(v, poly, t);
+    ct_round<LOGN, HL, 10, 4, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p);
+    store_coalesced<LOGN>(v, poly, t);
+}
+
+template <int HL, bool NEAR>
+__global__ void __launch_bounds__(64, 1)
+k_fwd15_rows(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+             unsigned prime_base)
+{
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
+    const unsigned y = blockIdx.x >> 4, wave = blockIdx.x & 15u, lane = threadIdx.x, t = (wave << 6) | lane;
+    const unsigned idx = prime_base + y % division;
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * G::N;
+    const BufRsrc twr = make_rsrc(twp, G::N * 16u);
+    u64* poly = a + (size_t)y * G::N;
+    const BufRsrc prs = make_rsrc(poly, G::N * 8u);
+    u64 v[32];
+    // layout 5: register r of thread t holds coefficient ((t >> 5) << 10) | (r << 5) | (t & 31)
+    const unsigned voff = (((t >> 5) << 10) | (t & 31u)) * 8u;
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = buf_load_u64(prs, voff, (unsigned)decltype(rc)::value * 256u); });
+    ct_round<LOGN, HL, 5, 4, NEAR>(v, twp, twr, t, p);
+    wave_transpose_5_to_0(v, slice, lane);
+    ct_round<LOGN, HL, 0, 4, NEAR>(v, twp, twr, t, p);
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
+    wave_store_rows(v, slice, prs, wave * 16384u, lane);
+}
+
+template <int HL, bool NEAR>
+__global__ void __launch_bounds__(64, 1)
+k_inv15_rows(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+             unsigned prime_base)
+{
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
+    const unsigned y = blockIdx.x >> 4, wave = blockIdx.x & 15u, lane = threadIdx.x, t = (wave << 6) | lane;
+    const unsigned idx = prime_base + y % division;
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * G::N;
+    const BufRsrc twr = make_rsrc(twp, G::N * 16u);
+    u64* poly = a + (size_t)y * G::N;
+    const BufRsrc prs = make_rsrc(poly, G::N * 8u);
+    u64 v[32];
+    wave_load_rows(v, slice, prs, wave * 16384u, lane);
+    gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p);
+    wave_transpose_0_to_5(v, slice, lane);
+    gs_round<LOGN, HL, 5, 0, NEAR>(v, twp, twr, t, p);
+    const unsigned voff = (((t >> 5) << 10) | (t & 31u)) * 8u;
+    static_for<32>([&](auto rc) { buf_store_u64(prs, voff, (unsigned)decltype(rc)::value * 256u, v[decltype(rc)::value]); });
+}
+
+template <int HL, bool NEAR>
+__global__ void __launch_bounds__(64, 1)
+k_inv15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+             unsigned prime_base)
+{
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    const unsigned y = blockIdx.x >> 4, t = ((blockIdx.x & 15u) << 6) | threadIdx.x;
+    const unsigned idx = prime_base + y % division;
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * G::N;
+    u64* poly = a + (size_t)y * G::N;
+    u64 v[32];
+    load_coalesced<LOGN>(v, poly, t);
+    gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p);
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+    store_coalesced<LOGN>(v, poly, t);
+}
+
+// below this many polynomials the two-launch latency path is used (the persistent kernels need >= one polynomial per CU
+// to pay off; at 16 one-wave workgroups per polynomial 64 polynomials already fill 1024 wave slots)
+constexpr unsigned kLatencyPathMaxPolys = 48;
+
 // ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
 template <int LOGN, int HL>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
@@ -333,6 +432,24 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
+        if (num <= kLatencyPathMaxPolys) {
+            dim3 g2(num * 16u), b2(64);
+#define MI355NTT_LAT2(K1, K2, H, N)                                                         \
+            do {                                                                            \
+                K1<H, N><<<g2, b2, 0, s>>>(d_a, tw, pr, division, base);                    \
+                K2<H, N><<<g2, b2, 0, s>>>(d_a, tw, pr, division, base);                    \
+            } while (0)
+            if (near) {
+                if (h >= 6) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 6, true);
+                else if (h >= 4) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 4, true);
+                else MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 2, true);
+            } else {
+                if (h >= 6) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 6, false);
+                else if (h >= 4) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 4, false);
+                else MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 2, false);
+            }
+            return hipGetLastError();
+        }
         if (near) {
             if (h >= 6) k_forward15<6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
             else if (h >= 4) k_forward15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -359,6 +476,19 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
+        if (num <= kLatencyPathMaxPolys) {
+            dim3 g2(num * 16u), b2(64);
+            if (near) {
+                if (h >= 6) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 6, true);
+                else if (h >= 4) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 4, true);
+                else MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 2, true);
+            } else {
+                if (h >= 6) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 6, false);
+                else if (h >= 4) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 4, false);
+                else MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 2, false);
+            }
+            return hipGetLastError();
+        }
         if (near) {
             if (h >= 6) k_inverse15<6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
             else if (h >= 4) k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
