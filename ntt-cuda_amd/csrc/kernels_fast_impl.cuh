@@ -5,6 +5,8 @@
 #include "modarith.cuh"
 #include "ntt_core.cuh"
 
+#include <cstdlib>
+
 namespace mi355ntt {
 
 // coalesced layout B0: register r of thread t holds coefficient (r << B0) | t; lane offset in a VGPR,
@@ -365,9 +367,16 @@ k_inv15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev*
     store_coalesced<LOGN>(v, poly, t);
 }
 
-// below this many polynomials the two-launch latency path is used (the persistent kernels need >= one polynomial per CU
+// up to this many polynomials the two-launch latency path is used (the persistent kernels need >= one polynomial per CU
 // to pay off; at 16 one-wave workgroups per polynomial 64 polynomials already fill 1024 wave slots)
-constexpr unsigned kLatencyPathMaxPolys = 48;
+inline unsigned latency_path_max_polys()
+{
+    static const unsigned v = [] {
+        const char* e = std::getenv("MI355NTT_LATENCY_PATH_MAX");     // tuning/debug override
+        return e ? (unsigned)std::strtoul(e, nullptr, 10) : 128u;   // measured crossover on MI355X ~150 polynomials
+    }();
+    return v;
+}
 
 // ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
 template <int LOGN, int HL>
@@ -432,7 +441,7 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
-        if (num <= kLatencyPathMaxPolys) {
+        if (num <= latency_path_max_polys()) {
             dim3 g2(num * 16u), b2(64);
 #define MI355NTT_LAT2(K1, K2, H, N)                                                         \
             do {                                                                            \
@@ -476,7 +485,7 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
-        if (num <= kLatencyPathMaxPolys) {
+        if (num <= latency_path_max_polys()) {
             dim3 g2(num * 16u), b2(64);
             if (near) {
                 if (h >= 6) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 6, true);

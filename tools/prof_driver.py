@@ -16,11 +16,13 @@ dev = torch.device("cuda", 0)
 ctx = ntt.NTTContext(32768, Q60, PSI60)
 a = synth(torch, batch, 32768, Q60, dev, 1)
 b = synth(torch, batch, 32768, Q60, dev, 2)
+# the same shape as bench.py: enough back-to-back launches for the clocks to settle (a handful of cold launches reads
+# ~10 % slow), so the per-kernel averages of `rocprofv3 --kernel-trace --stats` are comparable with bench.py's
 for _ in range(reps):
     ctx.forward_batch(a, batch)
     ctx.inverse_batch(a, batch)
 ctx.forward_batch(b, batch)
-for _ in range(reps):
+for _ in range(max(1, reps // 4)):
     ctx.polymul_batch(a, b, batch)
 torch.cuda.synchronize()
 print("done")
