@@ -121,6 +121,32 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 #define MI355NTT_PRIO_I3 2
 #endif
 #define MI355NTT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+// timing experiments only (tools/kbench.hip): fold the polynomial index so the batch stays in the MALL or in L2
+// Start-time stagger of the persistent workgroups: 8 phase groups, UNITS x 2048 cycles apart.  Every workgroup does the
+// same work, so without it all CUs load and store in the same instants and HBM sees bursts instead of a steady stream.
+// Measured on k_forward15 (tools/kbench.hip, warm): +7...10 % for 256...1024 polynomials with UNITS = 1 (at most
+// 6 us of delay), fading to +2 % at 2048 and nothing at 4096, where the workgroups drift apart by themselves; nothing
+// on k_inverse15 and -3 % on k_polymul15 at 256 polynomials, which are left alone.
+#ifndef MI355NTT_STAGGER_FWD
+#define MI355NTT_STAGGER_FWD 1
+#endif
+#ifndef MI355NTT_STAGGER_INV
+#define MI355NTT_STAGGER_INV 0
+#endif
+#ifndef MI355NTT_STAGGER_MUL
+#define MI355NTT_STAGGER_MUL 0
+#endif
+template <int UNITS>
+__device__ __forceinline__ void stagger_start()
+{
+    if constexpr (UNITS > 0) {
+        const unsigned ph = (blockIdx.x >> 3) & 7u;
+        for (unsigned i = 0; i < ph * UNITS; i++) __builtin_amdgcn_s_sleep(32);
+    }
+}
+#ifndef MI355NTT_POLY_SLOT
+#define MI355NTT_POLY_SLOT(y) (y)
+#endif
 
 // ================================================================================================
 // n = 2^15: one workgroup-wide exchange per transform, everything else wave-local (ntt_core.cuh).
@@ -139,7 +165,8 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
-    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    stagger_start<MI355NTT_STAGGER_FWD>();
+    load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, t);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     for (; y < num; y += gridDim.x) {
@@ -147,7 +174,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-        u64* poly = a + (size_t)y * G::N;
+        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
         MI355NTT_STAMP2(it, 0);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
         ct_round<LOGN, HL, 10, 4, NEAR>(v, twp, twr, t, p);
@@ -165,7 +192,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMP2(it, 5);
         wave_store_rows(v, slice, make_rsrc(poly, G::N * 8u), wave * 16384u, lane);
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, t);
         MI355NTT_STAMP2(it, 6);
         it++;
     }
@@ -185,7 +212,8 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
-    wave_load_rows(v, slice, make_rsrc(a + (size_t)y * G::N, G::N * 8u), wave * 16384u, lane);
+    stagger_start<MI355NTT_STAGGER_INV>();
+    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, G::N * 8u), wave * 16384u, lane);
     for (; y < num; y += gridDim.x) {
         unsigned t = t0;
         asm volatile("" : "+v"(t));      // thread-derived offsets are recomputed per polynomial, not kept live across the loop
@@ -195,7 +223,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-        u64* poly = a + (size_t)y * G::N;
+        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
         MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
         gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p);
         wave_transpose_0_to_5(v, slice, lane);
@@ -208,7 +236,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num)
-            wave_load_rows(v, slice, make_rsrc(a + (size_t)(y + gridDim.x) * G::N, G::N * 8u), wave * 16384u, lane);
+            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, G::N * 8u), wave * 16384u, lane);
     }
 }
 
@@ -224,6 +252,7 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
+    stagger_start<MI355NTT_STAGGER_MUL>();
     load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
     for (; y < num; y += gridDim.x) {
         const unsigned idx = y % division;

@@ -114,9 +114,17 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, u32 bytes)
     const u32 lo = __builtin_amdgcn_readfirstlane(lo32(b)), hi = __builtin_amdgcn_readfirstlane(hi32(b));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((u64)hi << 32) | lo), 0, bytes, 0x00020000);
 }
+// Cache policy of the polynomial stream (aux bits of the buffer instructions: 2 = nt).  Every coefficient is read once
+// and written once per launch, the twiddle tables are re-read by every workgroup: keep the stream from evicting them.
+#ifndef MI355NTT_STREAM_AUX_LD
+#define MI355NTT_STREAM_AUX_LD 2
+#endif
+#ifndef MI355NTT_STREAM_AUX_ST
+#define MI355NTT_STREAM_AUX_ST 0
+#endif
 __device__ __forceinline__ u64 buf_load_u64(BufRsrc r, u32 voff, u32 soff)
 {
-    const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, MI355NTT_STREAM_AUX_LD);
     return (u64)x.x | ((u64)x.y << 32);
 }
 __device__ __forceinline__ void buf_store_u64(BufRsrc r, u32 voff, u32 soff, u64 v)
@@ -124,7 +132,7 @@ __device__ __forceinline__ void buf_store_u64(BufRsrc r, u32 voff, u32 soff, u64
     v2u32 x;
     x.x = lo32(v);
     x.y = hi32(v);
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, MI355NTT_STREAM_AUX_ST);
 }
 __device__ __forceinline__ TwPair buf_load_tw(BufRsrc r, u32 voff, u32 soff)
 {
@@ -142,8 +150,9 @@ __device__ __forceinline__ TwPair buf_load_tw(BufRsrc r, u32 voff, u32 soff)
 // y*w mod q, result congruent and in [0, 4q).  y: any 64-bit value.  wp = floor(w*2^64/q).
 // Quotient estimate from three of the four partial products (error <= 2), remainder as y*w + h*(2^64-q).
 //
-// (gfx950 issues 32-bit multiplies, 64-bit adds and 3-operand adds at half rate; a variant that chains four
-// v_mad_u64_u32 on the high word -- 6 instead of 8 instructions for the remainder -- measured no faster.)
+// (gfx950 issues 32-bit multiplies, 64-bit adds and 3-operand adds at half rate; v_mad_u64_u32 costs about 1.6x a
+// v_mul_lo_u32, so variants that chain four of them on the high word -- 6 instead of 8 instructions for the
+// remainder -- measured slower: tools/ubench_bfly.hip variants 5 and 9.)
 __device__ __forceinline__ u64 mul_shoup4(u64 y, u64 w, u64 wp, u64 nq)
 {
     u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
@@ -163,6 +172,28 @@ __device__ __forceinline__ u64 mul_shoup(u64 y, u64 w, u64 wp, u64 nq)
 {
     if constexpr (EXACT) return mul_shoup2(y, w, wp, nq);
     else return mul_shoup4(y, w, wp, nq);
+}
+
+// CT butterfly (a, b) <- (a + T, a + cq - T) with T = b*w mod q in [0, 4q) as in mul_shoup4, fused: `a` rides in the
+// 64-bit addend of the lo*lo multiply-adds, so a + T costs no add of its own, and the difference is formed as
+// (2a + cq) - (a + T) with one shift-add: 15 VALU instructions instead of 16 (+7.5 % in tools/ubench_bfly.hip, variant
+// 11 vs 1).  It keeps one more 64-bit value live per butterfly; measured on k_forward15: +3 % with the 7-instruction
+// partial reduction (general primes), -2 % with the 3-instruction one (NEAR), so ct_round uses it for the former only.
+// The two empty asm statements pin values the compiler would otherwise re-associate back.
+__device__ __forceinline__ void ct_bfly4(u64& a, u64& b, u64 w, u64 wp, u64 nq, u64 cq)
+{
+    const u64 U = a, y = b;
+    u64 D = (U << 1) + cq;
+    asm("" : "+v"(D));
+    const u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
+    const u32 w0 = lo32(w), w1 = hi32(w), n0 = lo32(nq), n1 = hi32(nq);
+    const u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    const u32 h0 = lo32(h), h1 = hi32(h);
+    const u64 acc = mad32(h0, n0, mad32(y0, w0, U));
+    u32 xh = hi32(acc) + y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
+    asm("" : "+v"(xh));
+    a = ((u64)xh << 32) | lo32(acc);
+    b = D - a;
 }
 
 // x in [0, B*q) (B*q < 2^64, B <= 66 or B*q < 2^(k+5)) -> congruent value in [0, 2q).
@@ -439,7 +470,7 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
             const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4));
             v4u32 x;
             x.x = lo32(pr.x); x.y = hi32(pr.x); x.z = lo32(pr.y); x.w = hi32(pr.y);
-            __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, MI355NTT_STREAM_AUX_ST);
         });
         wave_lds_fence();
     });
@@ -455,7 +486,7 @@ __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, 
     v4u32 x[8];
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        x[k] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + CH * 128u, 0);
+        x[k] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + CH * 128u, MI355NTT_STREAM_AUX_LD);
     });
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -513,7 +544,11 @@ __device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* 
         if constexpr (B == Geo<LOGN>::B0)                   // group index independent of the thread: scalar load
             W[k] = tw[len + u];
         else
+#ifdef MI355NTT_ABLATE_TWL1     // timing experiment: same loads, every address inside one 4 KiB window (always L1 hits)
+            W[k] = buf_load_tw(twr, (thi * 16u) & 0xff0u, (tw_dev_index(LOGN, B, j, len, 0, u) * 16u) & 0xff0u);
+#else
             W[k] = buf_load_tw(twr, thi * 16u, tw_dev_index(LOGN, B, j, len, 0, u) * 16u);
+#endif
 #endif
     });
 }
@@ -543,9 +578,17 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
             constexpr int r1 = r0 | (1 << j);
             u64 U = v[r0];
             if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
-            const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
-            v[r0] = U + Tm;
-            v[r1] = U + cq - Tm;
+            if constexpr (EX || NEAR) {
+                const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
+                v[r0] = U + Tm;
+                v[r1] = U + cq - Tm;
+            } else {
+                v[r0] = U;
+                ct_bfly4(v[r0], v[r1], Wc[k].w, Wc[k].wp, p.nq, cq);
+            }
+#ifdef MI355NTT_INNER_FENCE
+            if constexpr (VEC && ((k + 1) % MI355NTT_INNER_FENCE) == 0 && k + 1 < GROUP) __builtin_amdgcn_sched_barrier(0);
+#endif
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         if constexpr (g + 1 < NG) static_for<GROUP>([&](auto kc) { Wc[decltype(kc)::value] = Wn[decltype(kc)::value]; });

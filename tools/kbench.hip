@@ -33,6 +33,7 @@ int main(int argc, char** argv)
     d.mu = pp.mu; d.k = pp.k; d.red_sh1 = pp.k - 17; d.red_sh2 = 16; d.red_c = (u32)((((u128)1) << (31 + pp.k)) / q);
     d.delta = (u32)((1ull << pp.k) - q); d.near_sh = pp.k - 32; d.near_mask = (u32)((1ull << (pp.k - 32)) - 1);
     const int HLSEL = argc > 3 ? atoi(argv[3]) : 4;
+    const int warm = argc > 4 ? atoi(argv[4]) : 3;   // untimed launches first (the chip needs tens of ms of load to settle its clocks)
     u64* a; TwPair* dtw; PrimeDev* dp;
     CK(hipMalloc(&a, (size_t)num * n * 8));
     CK(hipMalloc(&dtw, n * sizeof(TwPair)));
@@ -51,7 +52,7 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int which = 0; which < 2; which++) {
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < warm; i++) {
             if (which == 0) launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
         }
         CK(hipDeviceSynchronize());

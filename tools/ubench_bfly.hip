@@ -154,6 +154,95 @@ __device__ __forceinline__ void bfly<8>(u64& x, u64& y, const Consts& c)
     y = d * c.w + h * c.nq;
 }
 
+// opaque pass-through: the compiler must keep all 64 bits of a mad result it would otherwise narrow to mul_lo + add
+#define KEEP64(v) asm("" : "+v"(v))
+
+// 9: CT butterfly, every multiply a v_mad_u64_u32: U rides in the accumulator of the lo*lo products, the four cross
+//    products accumulate in the LOW word of a second chain (its high word is junk), one v_add_u32 joins them
+template <>
+__device__ __forceinline__ void bfly<9>(u64& x, u64& y, const Consts& c)
+{
+    u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(c.wp), p1 = hi32(c.wp);
+    u32 w0 = lo32(c.w), w1 = hi32(c.w), n0 = lo32(c.nq), n1 = hi32(c.nq);
+    u64 U = x;
+    u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    u32 h0 = lo32(h), h1 = hi32(h);
+    u64 cr = mad32(y0, w1, 0);
+    KEEP64(cr);
+    cr = mad32(y1, w0, cr);
+    KEEP64(cr);
+    u64 acc = mad32(y0, w0, U);
+    cr = mad32(h0, n1, cr);
+    KEEP64(cr);
+    acc = mad32(h0, n0, acc);
+    cr = mad32(h1, n0, cr);
+    KEEP64(cr);
+    u32 xh = hi32(acc) + lo32(cr);
+    asm("" : "+v"(xh));
+    u64 X = ((u64)xh << 32) | lo32(acc);   // U + T
+    x = X;
+    y = (U << 1) + c.fourq - X;                                  // U + 4q - T
+}
+
+// 10: GS butterfly with the same multiply structure
+template <>
+__device__ __forceinline__ void bfly<10>(u64& x, u64& y, const Consts& c)
+{
+    u64 s = x + y;
+    u64 d = x - y + c.fourq;
+    u32 y0 = lo32(d), y1 = hi32(d), p0 = lo32(c.wp), p1 = hi32(c.wp);
+    u32 w0 = lo32(c.w), w1 = hi32(c.w), n0 = lo32(c.nq), n1 = hi32(c.nq);
+    u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    u32 h0 = lo32(h), h1 = hi32(h);
+    u64 cr = mad32(y0, w1, 0);
+    KEEP64(cr);
+    cr = mad32(y1, w0, cr);
+    KEEP64(cr);
+    u64 acc = mad32(y0, w0, 0);
+    cr = mad32(h0, n1, cr);
+    KEEP64(cr);
+    acc = mad32(h0, n0, acc);
+    cr = mad32(h1, n0, cr);
+    KEEP64(cr);
+    x = s;
+    u32 yh = hi32(acc) + lo32(cr);
+    asm("" : "+v"(yh));
+    y = ((u64)yh << 32) | lo32(acc);
+}
+
+// 11: variant 2 with U riding in the accumulator of the lo*lo products: x' = U + T needs no add of its own,
+//     y' = 2U + 4q - x'
+template <>
+__device__ __forceinline__ void bfly<11>(u64& x, u64& y, const Consts& c)
+{
+    u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(c.wp), p1 = hi32(c.wp);
+    u32 w0 = lo32(c.w), w1 = hi32(c.w), n0 = lo32(c.nq), n1 = hi32(c.nq);
+    u64 U = x;
+    u64 D = (U << 1) + c.fourq;
+    asm("" : "+v"(D));
+    u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    u32 h0 = lo32(h), h1 = hi32(h);
+    u64 acc = mad32(h0, n0, mad32(y0, w0, U));
+    u32 xh = hi32(acc) + y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
+    asm("" : "+v"(xh));
+    u64 X = ((u64)xh << 32) | lo32(acc);
+    x = X;
+    y = D - X;
+}
+
+// 12: variant 1 with per-chain twiddles held in VGPRs (as rounds 2 and 3 of the kernels have them)
+template <>
+__device__ __forceinline__ void bfly<12>(u64& x, u64& y, const Consts& c)
+{
+    u64 w = c.w ^ (x & 0), wp = c.wp;
+    u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
+    u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    u64 T = y * w + h * c.nq;
+    u64 U = x;
+    x = U + T;
+    y = U + c.fourq - T;
+}
+
 template <int V>
 __global__ void __launch_bounds__(1024) k_bfly(unsigned long long* out, const Consts* cp, int iters)
 {
@@ -167,16 +256,24 @@ __global__ void __launch_bounds__(1024) k_bfly(unsigned long long* out, const Co
         x[u] = (threadIdx.x * 1315423911ULL + u * 977ULL) & ((1ULL << 59) - 1);
         y[u] = (x[u] * 2654435761ULL + blockIdx.x) & ((1ULL << 59) - 1);
     }
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int u = 0; u < CH; u++) bfly<V>(x[u], y[u], c);
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     u64 s = 0;
     for (int u = 0; u < CH; u++) s ^= x[u] ^ y[u];
-    if (s == 0x12345678) out[1000000] = s + lds_pin[threadIdx.x];
-    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) / 64] = t1 - t0;
+    if (s == 0x12345678) out[4000000] = s + lds_pin[threadIdx.x];
+    // per wave: shader cycles in the loop, and the loop's start/end on the 100 MHz constant clock
+    if ((threadIdx.x & 63) == 0) {
+        size_t w_ = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+        out[3 * w_] = t1 - t0;
+        out[3 * w_ + 1] = r0;
+        out[3 * w_ + 2] = r1;
+    }
 }
 
 typedef void (*kern_t)(unsigned long long*, const Consts*, int);
@@ -188,7 +285,7 @@ static void run(const char* name, kern_t k, int block, int blocks_per_cu, int it
     int grid = prop.multiProcessorCount * blocks_per_cu;
     size_t nw = (size_t)grid * block / 64;
     unsigned long long* d;
-    CK(hipMalloc(&d, (nw + 8) * sizeof(unsigned long long) + 8000008));
+    CK(hipMalloc(&d, (3 * nw + 8) * sizeof(unsigned long long) + 32000008));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -204,18 +301,28 @@ static void run(const char* name, kern_t k, int block, int blocks_per_cu, int it
         CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, ms);
     }
-    std::vector<unsigned long long> h(nw);
-    CK(hipMemcpy(h.data(), d, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double avg = 0;
-    for (auto v : h) avg += (double)v;
+    std::vector<unsigned long long> h(3 * nw);
+    CK(hipMemcpy(h.data(), d, 3 * nw * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double avg = 0, avg_rt = 0;
+    unsigned long long first = ~0ULL, last = 0, last_start = 0;
+    for (size_t i = 0; i < nw; i++) {
+        avg += (double)h[3 * i];
+        avg_rt += (double)(h[3 * i + 2] - h[3 * i + 1]);
+        first = std::min(first, h[3 * i + 1]);
+        last_start = std::max(last_start, h[3 * i + 1]);
+        last = std::max(last, h[3 * i + 2]);
+    }
     avg /= nw;
+    avg_rt /= nw;
     double waves_per_simd = (double)block * blocks_per_cu / 256.0;
     double bf_per_wave = (double)iters * CH;
     double cyc = avg / (bf_per_wave * waves_per_simd);
     double total_bf = (double)grid * block * bf_per_wave;
     double rate = total_bf / (best * 1e-3);
-    printf("%-28s waves/SIMD=%2.0f  cyc/wave-bfly/SIMD=%6.2f  wall=%7.3f ms  clk=%.2f GHz  %.3e bfly/s  => %.2f M NTT(2^15)/s  (%4.1f%% of 15.26M)\n",
-           name, waves_per_simd, cyc, best, avg / (best * 1e6), rate, rate / 245760 / 1e6, rate / 245760 / 15.26e6 * 100);
+    // sclk = shader cycles per 100 MHz tick inside the loop; span = first wave's loop start .. last wave's loop end
+    printf("%-28s waves/SIMD=%2.0f  cyc/wave-bfly/SIMD=%6.2f  wall=%7.3f ms  loop(avg wave)=%7.3f ms  span=%7.3f ms  start skew=%6.3f ms  sclk=%.2f GHz  %.3e bfly/s  => %.2f M NTT(2^15)/s  (%4.1f%% of 15.26M)\n",
+           name, waves_per_simd, cyc, best, avg_rt / 1e5, (double)(last - first) / 1e5, (double)(last_start - first) / 1e5, avg / avg_rt * 0.1, rate,
+           rate / 245760 / 1e6, rate / 245760 / 15.26e6 * 100);
     CK(hipFree(d));
 }
 
@@ -237,6 +344,7 @@ int main(int argc, char** argv)
         {"0 shoup exact lazy", k_bfly<0>}, {"1 shoup approx (C)", k_bfly<1>}, {"2 shoup approx 32-bit (C)", k_bfly<2>},
         {"3 shoup exact harvey", k_bfly<3>}, {"4 barrett literal", k_bfly<4>}, {"5 shoup approx asm", k_bfly<5>},
         {"6 modmul approx only", k_bfly<6>}, {"7 GS harvey exact", k_bfly<7>}, {"8 GS approx lazy", k_bfly<8>},
+        {"9 CT all-mad fold", k_bfly<9>}, {"10 GS all-mad", k_bfly<10>}, {"11 CT fold U", k_bfly<11>},
     };
     for (auto& s : ks) {
         run(s.n, s.k, 256, 1, iters, dc);
