@@ -55,6 +55,9 @@ const char* mi355ntt_version(void);
  * ---------------------------------------------------------------------------------------------- */
 unsigned     mi355ntt_bit_length(mi355ntt_u64 q);                                   /* demo.cu:69 */
 mi355ntt_u64 mi355ntt_barrett_mu(mi355ntt_u64 q, unsigned bit_length);              /* 60bit_ntt_test.cu:47-49 */
+/* 1 when the reference's single-subtraction Barrett (singleBarrett, ntt_60bit.cuh:44-61) returns the canonical residue
+ * for EVERY product of two canonical operands mod q, 0 when it can come out q too large (see mi355ntt_ctx_create). */
+int          mi355ntt_barrett_is_exact(mi355ntt_u64 q);
 mi355ntt_u64 mi355ntt_mulmod(mi355ntt_u64 a, mi355ntt_u64 b, mi355ntt_u64 m);       /* host64x2 + operator%, uint128.h:278-341 */
 mi355ntt_u64 mi355ntt_modpow(mi355ntt_u64 a, mi355ntt_u64 e, mi355ntt_u64 m);       /* modpow128, helper.h:8-28 */
 mi355ntt_u64 mi355ntt_modinv(mi355ntt_u64 a, mi355ntt_u64 q);                       /* modinv128, helper.h:52-56 */
@@ -70,10 +73,23 @@ int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt
 /* ------------------------------------------------------------------------------------------------
  * Context: replaces the caller-side bootstrap (demo.cu:62-196: bit lengths, mu, psi^-1, psi tables,
  * cudaMemcpyToSymbol of q_cons/q_bit_cons/mu_cons, table upload).  Immutable after creation.
+ *
+ * Arithmetic contract.  The throughput kernels compute the exact transform and return canonical residues.  That equals
+ * what the reference's kernels print whenever its single-subtraction Barrett is exact for the modulus
+ * (mi355ntt_barrett_is_exact: every modulus the reference ships, every q = 2^k - d with d^2 << 2^k).  For the rare
+ * other primes (e.g. 68719230977, the second prime of decryption_test.cu) the reference occasionally returns q + r or,
+ * one butterfly later, a wrong residue; a context holding such a prime therefore runs the literal stage-per-launch
+ * kernels (same words as the reference, ~4x slower) unless MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES is passed to
+ * mi355ntt_ctx_create_ex, which selects the exact kernels regardless.
  * ---------------------------------------------------------------------------------------------- */
+#define MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES 1u
 int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
                         const mi355ntt_u64* q, const mi355ntt_u64* psi, int device);
+int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
+                           const mi355ntt_u64* q, const mi355ntt_u64* psi, int device, unsigned flags);
 int mi355ntt_ctx_destroy(mi355ntt_ctx* ctx);
+/* 1 when the transforms of this context run the literal (reference-arithmetic) kernels, see above */
+int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_n(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_num_primes(const mi355ntt_ctx* ctx);
 /* per-prime derived parameters; any out pointer may be NULL */

@@ -33,7 +33,33 @@ struct mi355ntt_ctx {
     u64* d_psi = nullptr;        // [P][n]  psi^bitrev(i)      (reference format, demo.cu:188-196)
     u64* d_psiinv = nullptr;     // [P][n]  psi^-bitrev(i)
     FastTables fast;             // tables of the throughput kernels (kernels_fast.hip)
+    bool literal = false;        // some prime is not barrett_exact and the caller did not ask for exact results:
+                                 // transforms run the stage-per-launch kernels with the reference's arithmetic
 };
+
+static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
+{
+    ModSet r;
+    std::memset(&r, 0, sizeof(r));
+    for (unsigned i = 0; i < division && base + i < kMaxPrimes; i++) {
+        r.q[i] = c->mods.q[base + i];
+        r.mu[i] = c->mods.mu[base + i];
+        r.k[i] = c->mods.k[base + i];
+    }
+    return r;
+}
+
+static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
+{
+    if (c->literal) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+    return fast_forward_batch(c->fast, d_a, num, division, base, s);
+}
+
+static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
+{
+    if (c->literal) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+    return fast_inverse_batch(c->fast, d_a, num, division, base, s);
+}
 
 static bool is_pow2(unsigned n) { return n && !(n & (n - 1)); }
 
@@ -64,6 +90,11 @@ const char* mi355ntt_version(void) { return "mi355ntt 0.1 (gfx950)"; }
 /* ---------------- host-only helpers ---------------- */
 unsigned mi355ntt_bit_length(mi355ntt_u64 q) { return bit_length(q); }
 mi355ntt_u64 mi355ntt_barrett_mu(mi355ntt_u64 q, unsigned k) { return (k == 0 || k > 63 || q == 0) ? 0 : barrett_mu(q, k); }
+int mi355ntt_barrett_is_exact(mi355ntt_u64 q)
+{
+    const unsigned k = bit_length(q);
+    return (k >= 3 && k <= 62 && barrett_single_subtraction_exact(q, k, barrett_mu(q, k))) ? 1 : 0;
+}
 mi355ntt_u64 mi355ntt_mulmod(mi355ntt_u64 a, mi355ntt_u64 b, mi355ntt_u64 m) { return m ? mulmod(a, b, m) : 0; }
 mi355ntt_u64 mi355ntt_modpow(mi355ntt_u64 a, mi355ntt_u64 e, mi355ntt_u64 m) { return m ? modpow(a, e, m) : 0; }
 mi355ntt_u64 mi355ntt_modinv(mi355ntt_u64 a, mi355ntt_u64 q) { return q > 2 ? modinv(a, q) : 0; }
@@ -105,6 +136,14 @@ int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt
 int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes, const mi355ntt_u64* q, const mi355ntt_u64* psi,
                         int device)
 {
+    return mi355ntt_ctx_create_ex(out, n, num_primes, q, psi, device, 0);
+}
+
+int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* c) { return (c && c->literal) ? 1 : 0; }
+
+int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, const mi355ntt_u64* q, const mi355ntt_u64* psi,
+                           int device, unsigned flags)
+{
     if (!out || !q || !psi) return MI355NTT_EINVAL;
     *out = nullptr;
     int rc = check_n(n);
@@ -127,6 +166,7 @@ int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes, con
         c->mods.q[i] = c->prime[i].q;
         c->mods.mu[i] = c->prime[i].mu;
         c->mods.k[i] = c->prime[i].k;
+        if (!c->prime[i].barrett_exact && !(flags & MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES)) c->literal = true;
     }
 
     auto fail = [&](int code) {
@@ -200,7 +240,7 @@ int mi355ntt_forward_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned nu
     int rc = check_batch(c, d_a, num, division);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
-    HIP_TRY(fast_forward_batch(c->fast, d_a, num, division, 0, (hipStream_t)s));
+    HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
@@ -209,21 +249,21 @@ int mi355ntt_inverse_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned nu
     int rc = check_batch(c, d_a, num, division);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
-    HIP_TRY(fast_inverse_batch(c->fast, d_a, num, division, 0, (hipStream_t)s));
+    HIP_TRY(run_inverse(c, d_a, num, division, 0, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
 int mi355ntt_forward(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream s)
 {
     if (!c || !d_a || prime_idx >= c->num_primes) return MI355NTT_EINVAL;
-    HIP_TRY(fast_forward_batch(c->fast, d_a, 1, 1, prime_idx, (hipStream_t)s));
+    HIP_TRY(run_forward(c, d_a, 1, 1, prime_idx, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
 int mi355ntt_inverse(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream s)
 {
     if (!c || !d_a || prime_idx >= c->num_primes) return MI355NTT_EINVAL;
-    HIP_TRY(fast_inverse_batch(c->fast, d_a, 1, 1, prime_idx, (hipStream_t)s));
+    HIP_TRY(run_inverse(c, d_a, 1, 1, prime_idx, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
@@ -262,6 +302,12 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355
     if (rc) return rc;
     if (!d_bhat) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
+    if (c->literal) {   // the reference's own sequence (bfv_encryption.cuh:268-271) on the literal kernels
+        HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
+        HIP_TRY(compat_pointwise(d_a, d_a, d_bhat, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s));
+        HIP_TRY(run_inverse(c, d_a, num, division, 0, (hipStream_t)s));
+        return MI355NTT_OK;
+    }
     HIP_TRY(fast_polymul_batch(c->fast, d_a, d_bhat, num, division, (hipStream_t)s));
     return MI355NTT_OK;
 }

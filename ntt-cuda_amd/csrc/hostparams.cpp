@@ -1,6 +1,8 @@
 // hostparams.cpp -- host-only parameter derivation (no HIP).
 #include "hostparams.hpp"
 
+#include <cmath>
+
 #include "../../include/mi355ntt.h"
 
 namespace mi355ntt {
@@ -11,6 +13,25 @@ unsigned bit_length(u64 q) { return q ? 64u - (unsigned)__builtin_clzll(q) : 0u;
 
 // 60bit_ntt_test.cu:47-49: mu = floor(2^(2k) / q)
 u64 barrett_mu(u64 q, unsigned k) { return (u64)((((u128)1) << (2 * k)) / q); }
+
+// The reference reduces a = x*y (x, y < q) as  s = ((a >> (k-2)) * mu) >> (k+2),  r = a - s*q,  r -= q if r >= q.
+// With 2^(2k)/q = mu + f (0 <= f < 1) and a/2^(k-2) = x1 + g (0 <= g < 1):  a/q - x1*mu/2^(k+2) = a*f/2^(2k) + g*mu/2^(k+2),
+// so the quotient estimate s is at most one short -- and the single subtraction enough -- whenever
+//     (q-1)^2 * f / 2^(2k)  +  mu / 2^(k+2)  <  1.
+// That holds for every modulus the reference ships and for every q = 2^k - d with d^2 << 2^k (then f ~ d^2/2^k), but
+// not for all primes: q = 68719230977 = 2^36 - 245759 (second prime of decryption_test.cu) has f = 0.88 and the
+// reference's transform returns q + r, or a wrong residue after the next butterfly's unsigned compare, for about
+// 6e-5 of uniform operand pairs (1.8 % when one operand is q - 1).  The exact lazy kernels return the canonical value
+// there, which is NOT what the reference prints, so contexts holding such a prime run the literal kernels by default.
+bool barrett_single_subtraction_exact(u64 q, unsigned k, u64 mu)
+{
+    if (k < 3 || k > 62 || q < 2) return false;
+    const u128 two2k = ((u128)1) << (2 * k);
+    const long double f = (long double)(u64)(two2k % q) / (long double)q;
+    const long double top = (long double)(q - 1) / ldexpl(1.0L, (int)k);
+    const long double bound = top * top * f + (long double)mu / ldexpl(1.0L, (int)k + 2);
+    return bound < 1.0L - 1e-9L;
+}
 
 u64 mulmod(u64 a, u64 b, u64 m) { return (u64)(((u128)a * b) % m); }
 
@@ -66,6 +87,7 @@ int derive_prime(unsigned n, u64 q, u64 psi, PrimeParams* out)
     out->psi = psi;
     out->k = bit_length(q);
     out->mu = barrett_mu(q, out->k);
+    out->barrett_exact = barrett_single_subtraction_exact(q, out->k, out->mu);
     out->psiinv = modinv(psi, q);       // demo.cu:96-97
     if (mulmod(out->psiinv, psi, q) != 1) return MI355NTT_EPARAM;  // q not prime
     out->ninv = modinv(n % q, q);

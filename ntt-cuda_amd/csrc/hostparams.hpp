@@ -19,10 +19,15 @@ u64 bit_reverse(u64 a, int bits);
 u64 shoup(u64 w, u64 q);
 void fill_table(u64 root, u64 q, unsigned n, u64* tab);
 
+// Does the reference's Barrett (Algorithm 7, ONE conditional subtraction: ntt_60bit.cuh:44-61) return the canonical
+// residue for every product of two canonical operands?  See hostparams.cpp.
+bool barrett_single_subtraction_exact(u64 q, unsigned k, u64 mu);
+
 // Everything the device kernels need for one prime.
 struct PrimeParams {
     u64 q, psi, psiinv, mu, ninv;
     unsigned k;
+    bool barrett_exact;   // barrett_single_subtraction_exact(q, k, mu)
 };
 
 // Validates (q, psi) for ring degree n; returns 0 or a negative MI355NTT_E* code.

@@ -38,7 +38,10 @@ _SIGNATURES = {
     "mi355ntt_bit_reverse": (u64, [u64, ctypes.c_int]),
     "mi355ntt_fill_tables": (ctypes.c_int, [u64, u64, u64, ctypes.c_uint, u64p, u64p]),
     "mi355ntt_get_params": (ctypes.c_int, [ctypes.c_uint, u64p, u64p, u64p, u64p, u32p]),
+    "mi355ntt_barrett_is_exact": (ctypes.c_int, [u64]),
     "mi355ntt_ctx_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, ctypes.c_int]),
+    "mi355ntt_ctx_create_ex": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, ctypes.c_int, ctypes.c_uint]),
+    "mi355ntt_ctx_uses_literal_kernels": (ctypes.c_int, [vp]),
     "mi355ntt_ctx_destroy": (ctypes.c_int, [vp]),
     "mi355ntt_ctx_n": (ctypes.c_uint, [vp]),
     "mi355ntt_ctx_num_primes": (ctypes.c_uint, [vp]),
@@ -96,6 +99,14 @@ def lib():
             f.argtypes = args
         _lib = L
     return _lib
+
+
+CTX_EXACT_ON_INEXACT_PRIMES = 1   # MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES
+
+
+def barrett_is_exact(q):
+    """1 when the reference's single-subtraction Barrett is exact for every pair of canonical operands mod q."""
+    return bool(lib().mi355ntt_barrett_is_exact(int(q)))
 
 
 def _check(code, where):
@@ -183,12 +194,16 @@ class NTTContext:
     """Immutable per-(n, primes) state: replaces the bootstrap at demo.cu:62-196 and the __constant__
     q_cons/q_bit_cons/mu_cons symbols (ntt_60bit.cuh:8-10)."""
 
-    def __init__(self, n, q, psi, device=0):
+    def __init__(self, n, q, psi, device=0, exact_on_inexact_primes=False):
+        """exact_on_inexact_primes: run the exact kernels even when some modulus makes the reference's single-subtraction
+        Barrett inexact (barrett_is_exact(q) == 0); by default such a context reproduces the reference's words with the
+        literal kernels (include/mi355ntt.h, "Arithmetic contract")."""
         self._h = vp()
         qs, ps = _np_u64(np.atleast_1d(q)), _np_u64(np.atleast_1d(psi))
         assert qs.size == ps.size
-        _check(lib().mi355ntt_ctx_create(ctypes.byref(self._h), int(n), int(qs.size), qs.ctypes.data_as(u64p),
-                                         ps.ctypes.data_as(u64p), int(device)), "mi355ntt_ctx_create")
+        _check(lib().mi355ntt_ctx_create_ex(ctypes.byref(self._h), int(n), int(qs.size), qs.ctypes.data_as(u64p),
+                                            ps.ctypes.data_as(u64p), int(device),
+                                            CTX_EXACT_ON_INEXACT_PRIMES if exact_on_inexact_primes else 0), "mi355ntt_ctx_create_ex")
         self.n = int(n)
         self.num_primes = int(qs.size)
         self.device = int(device)
@@ -203,6 +218,10 @@ class NTTContext:
             self.close()
         except Exception:
             pass
+
+    @property
+    def uses_literal_kernels(self):
+        return bool(lib().mi355ntt_ctx_uses_literal_kernels(self._h))
 
     def prime(self, i):
         q, mu, psi, psiinv = u64(), u64(), u64(), u64()

@@ -341,6 +341,104 @@ int orc_bfv_decrypt(u64* c, const u64* sk, const u64* qs, const u64* psis, unsig
     return 0;
 }
 
+/* ------------------------------------------- BFV key generation / encryption */
+
+/* Everything in keygen_rns / encryption_rns after the samplers (bfv_keygen.cuh:95-151, bfv_encryption.cuh:223-290).
+ * The sampled polynomials are inputs here (the samplers themselves are SURVEY.md 8f row 3).  r_plus_1 = number of
+ * primes INCLUDING the special last one ("q_amount" of these two drivers).  Parity of these two is pinned only through
+ * the round trip with orc_bfv_decrypt (itself pinned by KAT-1), as in demo.cu:302-311. */
+static void bfv_tables(const u64* qs, const u64* psis, unsigned R, unsigned n, u64** psi_tabs, u64** psiinv_tabs,
+                       u64* mus, unsigned* kbits)
+{
+    *psi_tabs = (u64*)malloc(sizeof(u64) * (size_t)n * R);
+    *psiinv_tabs = (u64*)malloc(sizeof(u64) * (size_t)n * R);
+    for (unsigned i = 0; i < R; i++) {
+        kbits[i] = orc_bit_length(qs[i]);
+        mus[i] = orc_mu(qs[i], kbits[i]);
+        orc_fill_table(psis[i], qs[i], *psi_tabs + (size_t)i * n, n);
+        orc_fill_table(orc_modinv(psis[i], qs[i]), qs[i], *psiinv_tabs + (size_t)i * n, n);
+    }
+}
+
+/* secret_key [R][n]: ternary sample in, NTT domain out.  public_key [2][R][n]: second half = uniform sample (never
+ * transformed: it is used as if already in the NTT domain), first half out = NTT(-(a*s + e)).  e [R][n]. */
+int orc_bfv_keygen_core(u64* secret_key, u64* public_key, const u64* e, const u64* qs, const u64* psis,
+                        unsigned r_plus_1, unsigned n)
+{
+    unsigned R = r_plus_1;
+    if (R > 16 || R < 2) return -1;
+    unsigned kbits[16]; u64 mus[16];
+    u64 *psi_tabs, *psiinv_tabs;
+    bfv_tables(qs, psis, R, n, &psi_tabs, &psiinv_tabs, mus, kbits);
+    orc_forward_batch(secret_key, n, psi_tabs, R, R, qs, mus, kbits, 1);                          /* bfv_keygen.cuh:129 */
+    orc_pointwise_batch(public_key, public_key + (size_t)R * n, secret_key, n, R, R, qs, mus, kbits);   /* :131-132 */
+    orc_inverse_batch(public_key, n, psiinv_tabs, R, R, qs, mus, kbits, 1);                       /* :133 */
+    for (size_t i = 0; i < (size_t)R * n; i++) {                                                  /* poly_add_negate_xq, :80-93 */
+        u64 q = qs[i / n];
+        u64 ra = public_key[i] + e[i];
+        if (ra >= q) ra -= q;
+        ra = q - ra;
+        public_key[i] = ra * (ra != q);
+    }
+    orc_forward_batch(public_key, n, psi_tabs, R, R, qs, mus, kbits, 1);                          /* :145 */
+    free(psi_tabs); free(psiinv_tabs);
+    return 0;
+}
+
+/* c [2][R][n]: the ternary sample u in both halves on entry, the ciphertext (c0 | c1, last prime's slots dropped but
+ * still present) on return.  public_key [2][R][n] (NTT domain), e [2][R][n], m [n] (message, values below t). */
+int orc_bfv_encrypt_core(u64* c, const u64* public_key, const u64* e, const u64* m, const u64* qs, const u64* psis,
+                         unsigned r_plus_1, unsigned n, u64 t)
+{
+    unsigned R = r_plus_1, r = R - 1;
+    if (R > 16 || R < 2) return -1;
+    unsigned kbits[16]; u64 mus[16];
+    u64 *psi_tabs, *psiinv_tabs;
+    bfv_tables(qs, psis, R, n, &psi_tabs, &psiinv_tabs, mus, kbits);
+    orc_forward_batch(c, n, psi_tabs, 2 * R, R, qs, mus, kbits, 1);                               /* bfv_encryption.cuh:268 */
+    orc_pointwise_batch(c, c, public_key, n, 2 * R, R, qs, mus, kbits);                           /* :269-270 */
+    orc_inverse_batch(c, n, psiinv_tabs, 2 * R, R, qs, mus, kbits, 1);                            /* :271 */
+    for (unsigned h = 0; h < 2; h++)                                                              /* poly_add_xq, :173-184 (`>`) */
+        for (size_t i = 0; i < (size_t)R * n; i++) {
+            size_t x = i + (size_t)n * R * h;
+            u64 ra = c[x] + e[x];
+            if (ra > qs[i / n]) ra -= qs[i / n];
+            c[x] = ra;
+        }
+    u64 last_modulus = qs[R - 1], half_last = last_modulus >> 1;
+    for (size_t i = 0; i < (size_t)2 * n; i++) {                                                  /* divide_and_round_q_last_inplace_add_x2, :110-124 */
+        size_t x = (size_t)n * (R - 1) + i % n + ((size_t)n * R) * (i >= n);
+        u64 ra = c[x] + half_last;
+        if (ra >= last_modulus) ra -= last_modulus;
+        c[x] = ra;
+    }
+    for (size_t i = 0; i < (size_t)2 * n * r; i++) {                                              /* divide_and_round_q_last_inplace_loop_xq, :126-171 */
+        size_t i_i = i % n;
+        unsigned index = (unsigned)((i % ((size_t)n * r)) / n);
+        u64 q = qs[index];
+        u64 half_mod = half_last % q;
+        u64 iql = orc_modinv(qs[R - 1] % q, q);                                                   /* demo.cu:77 */
+        unsigned second_half = i >= (size_t)n * r;
+        size_t division = (i - (size_t)n * second_half * r) / n;
+        u64* rns_poly_minus1 = c + (size_t)second_half * ((size_t)n * R) + (size_t)n * r;
+        u64* input_poly = c + (size_t)second_half * ((size_t)n * R) + (size_t)n * division;
+        u64 temp_poly_i = rns_poly_minus1[i_i] % q;
+        if (temp_poly_i < half_mod) temp_poly_i += q;
+        temp_poly_i -= half_mod;
+        if (input_poly[i_i] < temp_poly_i) input_poly[i_i] += q;
+        input_poly[i_i] -= temp_poly_i;
+        input_poly[i_i] = barrett128((u128)input_poly[i_i] * iql, q, mus[index], kbits[index]);
+    }
+    for (unsigned j = 0; j < n; j++) {                                                            /* weird_m_stuff, :186-208 */
+        u64 numerator = m[j] + ((t + 1) >> 1);
+        u64 fix = numerator / t;
+        for (unsigned i = 0; i < r; i++)
+            c[j + (size_t)i * n] = (c[j + (size_t)i * n] + ((m[j] * (qs[i] / t)) + fix)) % qs[i];  /* qi_div_t: demo.cu:84-88 */
+    }
+    free(psi_tabs); free(psiinv_tabs);
+    return 0;
+}
+
 /* -------------------------------------------------------- synthetic inputs */
 
 /* splitmix64, state x0 = seed, value = z mod q */

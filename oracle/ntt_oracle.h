@@ -69,6 +69,12 @@ void orc_ref_polymul(const u64* a, const u64* b, u64* d, u64 m, unsigned n);    
  * after inverse batch. */
 int orc_bfv_decrypt(u64* c, const u64* sk, const u64* qs, const u64* psis, unsigned r_plus_1,
                     unsigned n, u64 t, u64 gamma, u64* out, u64* stage_out);
+/* keygen_rns / encryption_rns after their samplers (bfv_keygen.cuh:95-151, bfv_encryption.cuh:223-290); r_plus_1 counts
+ * the special last prime.  Pinned through the round trip with orc_bfv_decrypt (demo.cu:302-311). */
+int orc_bfv_keygen_core(u64* secret_key, u64* public_key, const u64* e, const u64* qs, const u64* psis,
+                        unsigned r_plus_1, unsigned n);
+int orc_bfv_encrypt_core(u64* c, const u64* public_key, const u64* e, const u64* m, const u64* qs, const u64* psis,
+                         unsigned r_plus_1, unsigned n, u64 t);
 
 /* constants the bootstrap derives, exposed for the known-answer checks
  * (old/decryption.cu:46,97,103,113; old/encryption.cu:98,101) */

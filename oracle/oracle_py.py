@@ -70,6 +70,10 @@ def lib():
         L.orc_ref_polymul.argtypes = [u64p, u64p, u64p, u64, ctypes.c_uint]
         L.orc_bfv_decrypt.restype = ctypes.c_int
         L.orc_bfv_decrypt.argtypes = [u64p, u64p, u64p, u64p, ctypes.c_uint, ctypes.c_uint, u64, u64, u64p, u64p]
+        L.orc_bfv_keygen_core.restype = ctypes.c_int
+        L.orc_bfv_keygen_core.argtypes = [u64p, u64p, u64p, u64p, u64p, ctypes.c_uint, ctypes.c_uint]
+        L.orc_bfv_encrypt_core.restype = ctypes.c_int
+        L.orc_bfv_encrypt_core.argtypes = [u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_uint, ctypes.c_uint, u64]
         L.orc_bfv_constants.restype = None
         L.orc_bfv_constants.argtypes = [u64p, u64p, ctypes.c_uint, u64, u64, u64p, u64p, u64p, u64p, u64p, u64p]
         L.orc_splitmix_fill.restype = None
@@ -186,6 +190,43 @@ def bfv_decrypt(c, sk, qs, psis, n, t, gamma, want_stages=False):
                                _p(stages) if want_stages else None)
     assert rc == 0
     return (out, stages) if want_stages else out
+
+
+def bfv_keygen_core(sk, pk, e, qs, psis, n):
+    """keygen_rns after its samplers: returns (secret key in the NTT domain [R][n], public key [2][R][n])."""
+    sk = np.ascontiguousarray(sk, dtype=np.uint64).copy()
+    pk = np.ascontiguousarray(pk, dtype=np.uint64).copy()
+    e = np.ascontiguousarray(e, dtype=np.uint64)
+    qs = np.array(qs, dtype=np.uint64)
+    psis = np.array(psis, dtype=np.uint64)
+    assert lib().orc_bfv_keygen_core(_p(sk), _p(pk), _p(e), _p(qs), _p(psis), len(qs), n) == 0
+    return sk, pk
+
+
+def bfv_encrypt_core(c, pk, e, m, qs, psis, n, t):
+    """encryption_rns after its samplers: c holds the ternary sample u in both halves; returns the ciphertext."""
+    c = np.ascontiguousarray(c, dtype=np.uint64).copy()
+    pk = np.ascontiguousarray(pk, dtype=np.uint64)
+    e = np.ascontiguousarray(e, dtype=np.uint64)
+    m = np.ascontiguousarray(m, dtype=np.uint64)
+    qs = np.array(qs, dtype=np.uint64)
+    psis = np.array(psis, dtype=np.uint64)
+    assert lib().orc_bfv_encrypt_core(_p(c), _p(pk), _p(e), _p(m), _p(qs), _p(psis), len(qs), n, int(t)) == 0
+    return c
+
+
+def bfv_sample(qs, n, seed):
+    """Test inputs shaped like the reference's samplers' outputs (NOT its Salsa20 stream): a ternary polynomial
+    {0, 1, q-1} repeated per prime, small centred errors as residues, and uniform residues."""
+    rng = np.random.default_rng(seed)
+    R = len(qs)
+    tern = rng.integers(-1, 2, size=n)
+    def residues(x):
+        return np.stack([np.where(x < 0, np.uint64(q) - (-x).astype(np.uint64), x.astype(np.uint64)).astype(np.uint64) for q in qs])
+    def err(count):
+        return [np.rint(rng.normal(0, 3.2, size=n)).astype(np.int64) for _ in range(count)]
+    uniform = np.stack([rng.integers(0, q, size=n, dtype=np.uint64) for q in qs])
+    return dict(ternary=residues(tern), err=lambda: residues(err(1)[0]), uniform=uniform, rng=rng)
 
 
 def bfv_constants(qs, psis, t, gamma):

@@ -137,3 +137,25 @@ def test_batch_index_rules(oracle):
     assert np.array_equal(oracle.inverse_batch(F, prm, division=3).reshape(5, n), x)
     # OpenMP batch == serial batch
     assert np.array_equal(oracle.forward_batch(x, prm, division=3, threads=4).reshape(5, n), F)
+
+
+def test_bfv_keygen_encrypt_decrypt_round_trip(oracle):
+    """demo.cu:302-311: the only check the reference has for keygen_rns / encryption_rns is that decryption returns the
+    message.  Same here for the restatements (decryption itself is pinned by KAT-1 above), on three of the reference's
+    55-bit demo moduli (demo.cu:35-36) at n = 4096.  (Not on the KAT-1 moduli: the second of them makes the reference's
+    Barrett inexact, and with ternary inputs its own round trip breaks -- tests/test_barrett_exactness.py.)"""
+    n, t, gamma = 4096, 1024, P.GAMMA61
+    qs = P.Q55[:3]
+    psis = [pow(psi, 32768 // n, q) for psi, q in zip(P.PSI55, qs)]
+    R = len(qs)
+    for seed in (1, 2, 3):
+        smp = oracle.bfv_sample(qs, n, seed)
+        pk = np.zeros((2, R, n), dtype=np.uint64)
+        pk[1] = smp["uniform"]
+        sk_hat, pk_hat = oracle.bfv_keygen_core(smp["ternary"], pk, smp["err"](), qs, psis, n)
+        m = smp["rng"].integers(0, t, size=n, dtype=np.uint64)
+        u = oracle.bfv_sample(qs, n, seed + 100)["ternary"]
+        e = np.stack([smp["err"](), smp["err"]()])
+        c = oracle.bfv_encrypt_core(np.stack([u, u]), pk_hat, e, m, qs, psis, n, t)
+        got = oracle.bfv_decrypt(c.reshape(-1), sk_hat.reshape(-1)[: (R - 1) * n], qs, psis, n, t, gamma)
+        assert np.array_equal(got, m)
