@@ -154,6 +154,39 @@ int mi355ntt_barrett_raw(mi355ntt_u64* d_c, const mi355ntt_u64* d_a, const mi355
 int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_u64 q, mi355ntt_u64 mu,
                              int bit_length, mi355ntt_stream stream);                             /* barrett_int :100 */
 
+/* ------------------------------------------------------------------------------------------------
+ * BFV launch layer around the NTT path: the parameter bootstrap of demo.cu:62-272 and the
+ * drivers keygen_rns / encryption_rns / decryption_rns AFTER their samplers -- the sampled polynomials are inputs (the
+ * Salsa20 / Gaussian samplers of distributions.cuh stay with the caller).  num_primes counts the special last prime
+ * that encryption drops ("q_amount" of keygen_rns / encryption_rns; decryption_rns is called with q_amount - 1).
+ * Layouts are the reference's: secret key [num_primes][n], public key and ciphertext [2][num_primes][n].
+ * Requires t a power of two with q_i = 1 (mod t) ("q mod t is assumed 1", bfv_encryption.cuh:189) and gamma odd < 2^62.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mi355ntt_bfv mi355ntt_bfv;
+/* ctx_flags: as mi355ntt_ctx_create_ex (the object owns an NTT context over all num_primes primes) */
+int mi355ntt_bfv_create(mi355ntt_bfv** out, unsigned n, unsigned num_primes, const mi355ntt_u64* q, const mi355ntt_u64* psi,
+                        mi355ntt_u64 t, mi355ntt_u64 gamma, int device, unsigned ctx_flags);
+int mi355ntt_bfv_destroy(mi355ntt_bfv* bfv);
+const mi355ntt_ctx* mi355ntt_bfv_ntt(const mi355ntt_bfv* bfv);
+/* the bootstrap constants (host arrays; any pointer may be NULL): inv_punctured_q[r], neg_inv_q_mod_t_gamma[2],
+ * prod_t_gamma_mod_q[r], inv_q_last_mod_q[r], q_div_t[r + 1], base_change_matrix[2][r], mu_gamma; r = num_primes - 1
+ * (demo.cu:73-79, 84-88, 103-125, 218-226, 262-301) */
+int mi355ntt_bfv_constants(const mi355ntt_bfv* bfv, mi355ntt_u64* inv_punctured_q, mi355ntt_u64* neg_inv_q_mod_t_gamma,
+                           mi355ntt_u64* prod_t_gamma_mod_q, mi355ntt_u64* inv_q_last_mod_q, mi355ntt_u64* q_div_t,
+                           mi355ntt_u64* base_change_matrix, mi355ntt_u64* mu_gamma);
+/* keygen_rns (bfv_keygen.cuh:95-151) from :129 on.  In: d_secret_key = the ternary sample as residues, second half of
+ * d_public_key = the uniform sample, d_e [num_primes][n] = the error sample.  Out: secret key and both halves of the
+ * public key in the NTT domain. */
+int mi355ntt_bfv_keygen(const mi355ntt_bfv* bfv, mi355ntt_u64* d_secret_key, mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
+                        mi355ntt_stream stream);
+/* encryption_rns (bfv_encryption.cuh:223-290) from :268 on.  In: d_c = the ternary sample u in both halves,
+ * d_e [2][num_primes][n], d_m [n] (message, values < t).  Out: the ciphertext in d_c (slots of the last prime unused). */
+int mi355ntt_bfv_encrypt(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
+                         const mi355ntt_u64* d_m, mi355ntt_stream stream);
+/* decryption_rns (bfv_decryption.cuh:76-138).  d_secret_key: first num_primes - 1 polynomials of the NTT-domain key.
+ * d_c is overwritten exactly as the reference overwrites it; the plaintext is at d_c + n * (num_primes - 2). */
+int mi355ntt_bfv_decrypt(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_secret_key, mi355ntt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,8 @@
 // their NTT hot path is the triple forwardNTT_batch -> barrett_batch* -> inverseNTT_batch on the legacy default
 // stream.  These functions are those call sites (same buffer layouts, same num/division arguments), issued on the
 // caller's stream through the throughput kernels of libmi355ntt.  Everything around them in the drivers
-// (samplers, poly_add_*, divide_and_round_*, base conversion) is outside the NTT path and stays with the caller.
+// (samplers, poly_add_*, divide_and_round_*, base conversion) is outside the NTT path; the element-wise part of it is
+// available through the drivers at the end of this file, the samplers stay with the caller.
 #pragma once
 #include "../../include/mi355ntt.h"
 
@@ -42,6 +43,30 @@ inline int decryption_ntt(const mi355ntt_ctx* ctx, unsigned long long* c, const 
                           unsigned q_amount, mi355ntt_stream stream)
 {
     return mi355ntt_polymul_batch(ctx, c + (size_t)(q_amount + 1) * n, secret_key, q_amount, q_amount + 1, stream);
+}
+
+// ---- the whole drivers after their samplers (C ABI section "BFV"): the element-wise kernels around the NTT sections
+// (poly_add_negate_xq, poly_add_xq, divide_and_round_q_last_inplace_*, weird_m_stuff, poly_add_xq_d,
+// poly_mul_int_xq_*, fast_convert_array_kernels, poly_mul_int(_t), dec_round) run fused on the same stream ----
+
+// keygen_rns from bfv_keygen.cuh:129 on; temp = the error sample
+inline int keygen_rns(const mi355ntt_bfv* bfv, unsigned long long* secret_key, unsigned long long* public_key,
+                      const unsigned long long* temp, mi355ntt_stream stream)
+{
+    return mi355ntt_bfv_keygen(bfv, secret_key, public_key, temp, stream);
+}
+
+// encryption_rns from bfv_encryption.cuh:268 on
+inline int encryption_rns(const mi355ntt_bfv* bfv, unsigned long long* c, const unsigned long long* public_key,
+                          const unsigned long long* e, const unsigned long long* m_poly_device, mi355ntt_stream stream)
+{
+    return mi355ntt_bfv_encrypt(bfv, c, public_key, e, m_poly_device, stream);
+}
+
+// decryption_rns (bfv_decryption.cuh:76-138); plaintext at c + n * (q_amount - 1), q_amount = primes without the special one
+inline int decryption_rns(const mi355ntt_bfv* bfv, unsigned long long* c, const unsigned long long* secret_key, mi355ntt_stream stream)
+{
+    return mi355ntt_bfv_decrypt(bfv, c, secret_key, stream);
 }
 
 }  // namespace mi355

@@ -1,0 +1,202 @@
+// bfv_host.cpp -- parameter bootstrap and drivers of the BFV launch layer (C ABI section "BFV" of include/mi355ntt.h).
+// The drivers are the reference's launch sequences (bfv_keygen.cuh:95-151, bfv_encryption.cuh:223-290,
+// bfv_decryption.cuh:76-138) after their samplers, issued on the caller's stream: NTT sections through the public
+// transforms of the context, element-wise steps through kernels_bfv.hip.
+#include "../../include/mi355ntt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "bfv.hpp"
+
+using namespace mi355ntt;
+
+namespace mi355ntt {
+
+int bfv_bootstrap(BfvParams* out, unsigned n, unsigned R, const u64* q, u64 t, u64 gamma)
+{
+    if (R < 2 || R > kMaxPrimes) return MI355NTT_EUNSUPPORTED;
+    if (t < 2 || (t & (t - 1)) != 0 || t > (1ull << 31)) return MI355NTT_EUNSUPPORTED;   // masks: `unsigned mask = t - 1`
+    const unsigned gbits = bit_length(gamma);
+    if (gbits < 3 || gbits > 62 || (gamma & 1) == 0) return MI355NTT_EUNSUPPORTED;
+    BfvParams p;
+    p.n = n;
+    p.R = R;
+    p.r = R - 1;
+    p.t = t;
+    p.gamma = gamma;
+    p.gamma_bits = gbits;                          // output_base_bit_lengths[1] (61 for the reference's gamma, demo.cu:100)
+    p.mu_gamma = barrett_mu(gamma, gbits);         // demo.cu:218-226
+    p.gamma_div_2 = gamma >> 1;                    // demo.cu:94
+    p.q_last = q[R - 1];
+    p.half_q_last = p.q_last >> 1;
+    const unsigned r = p.r;
+    u64 mult_t = 1, mult_g = 1;                    // demo.cu:103-117
+    for (unsigned i = 0; i < r; i++) {
+        if (q[i] % t != 1) return MI355NTT_EPARAM;   // "q mod t is assumed 1", bfv_encryption.cuh:189
+        if (q[i] % gamma == 0) return MI355NTT_EPARAM;
+        mult_t = mulmod(mult_t, q[i], t);
+        mult_g = mulmod(mult_g, q[i], gamma);
+    }
+    p.neg_inv_q_mod_t = t - modpow(mult_t, t - 2, t);          // the reference's modinv128 is a^(m-2) for every modulus
+    p.neg_inv_q_mod_gamma = gamma - modinv(mult_g, gamma);
+    const u128 prod_t_gamma = (u128)t * gamma;                 // demo.cu:119-125
+    for (unsigned i = 0; i < R; i++) {
+        BfvPrime& bp = p.prime[i];
+        std::memset(&bp, 0, sizeof(bp));
+        bp.q = q[i];
+        bp.k = bit_length(q[i]);
+        bp.mu = barrett_mu(q[i], bp.k);
+        bp.q_div_t = q[i] / t;                                 // demo.cu:84-88
+        if (i < r) {
+            bp.prod_t_gamma_mod_q = (u64)(prod_t_gamma % q[i]);
+            u64 punct = 1;                                     // demo.cu:262-276
+            for (unsigned j = 0; j < r; j++)
+                if (j != i) punct = mulmod(punct, q[j], q[i]);
+            bp.inv_punctured_q = modinv(punct, q[i]);
+            bp.inv_q_last_mod_q = modinv(q[R - 1] % q[i], q[i]);   // demo.cu:73-79
+            bp.half_last_mod_q = p.half_q_last % q[i];
+        }
+    }
+    const u64 base[2] = {t, gamma};                            // demo.cu:281-301
+    for (unsigned b = 0; b < 2; b++)
+        for (unsigned j = 0; j < r; j++) {
+            u64 temp = 1;
+            for (unsigned kk = 0; kk < r; kk++)
+                if (kk != j) temp = mulmod(temp, q[kk], base[b]);
+            p.base_change[b * r + j] = temp;
+        }
+    *out = p;
+    return MI355NTT_OK;
+}
+
+}  // namespace mi355ntt
+
+static thread_local int g_bfv_hip_error = 0;
+
+struct mi355ntt_bfv {
+    mi355ntt_ctx* ntt = nullptr;
+    BfvParams p;
+    BfvDevice d;
+    void* d_prime = nullptr;
+    void* d_bcm = nullptr;
+};
+
+#define BFV_HIP(expr)                         \
+    do {                                      \
+        hipError_t e__ = (expr);              \
+        if (e__ != hipSuccess) {              \
+            g_bfv_hip_error = (int)e__;       \
+            return MI355NTT_EHIP;             \
+        }                                     \
+    } while (0)
+#define BFV_RC(expr)            \
+    do {                        \
+        int rc__ = (expr);      \
+        if (rc__) return rc__;  \
+    } while (0)
+
+extern "C" {
+
+int mi355ntt_bfv_create(mi355ntt_bfv** out, unsigned n, unsigned num_primes, const mi355ntt_u64* q, const mi355ntt_u64* psi,
+                        mi355ntt_u64 t, mi355ntt_u64 gamma, int device, unsigned ctx_flags)
+{
+    if (!out || !q || !psi) return MI355NTT_EINVAL;
+    *out = nullptr;
+    mi355ntt_bfv* b = new (std::nothrow) mi355ntt_bfv();
+    if (!b) return MI355NTT_ENOMEM;
+    int rc = bfv_bootstrap(&b->p, n, num_primes, q, t, gamma);
+    if (!rc) rc = mi355ntt_ctx_create_ex(&b->ntt, n, num_primes, q, psi, device, ctx_flags);
+    if (rc) {
+        mi355ntt_bfv_destroy(b);
+        return rc;
+    }
+    hipError_t e;
+    if ((e = hipMalloc(&b->d_prime, sizeof(BfvPrime) * num_primes)) != hipSuccess ||
+        (e = hipMalloc(&b->d_bcm, sizeof(u64) * 2 * b->p.r)) != hipSuccess ||
+        (e = hipMemcpy(b->d_prime, b->p.prime, sizeof(BfvPrime) * num_primes, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(b->d_bcm, b->p.base_change, sizeof(u64) * 2 * b->p.r, hipMemcpyHostToDevice)) != hipSuccess) {
+        g_bfv_hip_error = (int)e;
+        mi355ntt_bfv_destroy(b);
+        return e == hipErrorOutOfMemory ? MI355NTT_ENOMEM : MI355NTT_EHIP;
+    }
+    b->d.d_prime = static_cast<const BfvPrime*>(b->d_prime);
+    b->d.d_base_change = static_cast<const u64*>(b->d_bcm);
+    *out = b;
+    return MI355NTT_OK;
+}
+
+int mi355ntt_bfv_destroy(mi355ntt_bfv* b)
+{
+    if (!b) return MI355NTT_OK;
+    if (b->d_prime) (void)hipFree(b->d_prime);
+    if (b->d_bcm) (void)hipFree(b->d_bcm);
+    if (b->ntt) mi355ntt_ctx_destroy(b->ntt);
+    delete b;
+    return MI355NTT_OK;
+}
+
+const mi355ntt_ctx* mi355ntt_bfv_ntt(const mi355ntt_bfv* b) { return b ? b->ntt : nullptr; }
+
+int mi355ntt_bfv_constants(const mi355ntt_bfv* b, mi355ntt_u64* inv_punctured_q, mi355ntt_u64* neg_inv_q_mod_t_gamma,
+                           mi355ntt_u64* prod_t_gamma_mod_q, mi355ntt_u64* inv_q_last_mod_q, mi355ntt_u64* q_div_t,
+                           mi355ntt_u64* base_change_matrix, mi355ntt_u64* mu_gamma)
+{
+    if (!b) return MI355NTT_EINVAL;
+    const BfvParams& p = b->p;
+    for (unsigned i = 0; i < p.r; i++) {
+        if (inv_punctured_q) inv_punctured_q[i] = p.prime[i].inv_punctured_q;
+        if (prod_t_gamma_mod_q) prod_t_gamma_mod_q[i] = p.prime[i].prod_t_gamma_mod_q;
+        if (inv_q_last_mod_q) inv_q_last_mod_q[i] = p.prime[i].inv_q_last_mod_q;
+    }
+    for (unsigned i = 0; i < p.R; i++)
+        if (q_div_t) q_div_t[i] = p.prime[i].q_div_t;
+    if (neg_inv_q_mod_t_gamma) {
+        neg_inv_q_mod_t_gamma[0] = p.neg_inv_q_mod_t;
+        neg_inv_q_mod_t_gamma[1] = p.neg_inv_q_mod_gamma;
+    }
+    if (base_change_matrix)
+        for (unsigned i = 0; i < 2 * p.r; i++) base_change_matrix[i] = p.base_change[i];
+    if (mu_gamma) *mu_gamma = p.mu_gamma;
+    return MI355NTT_OK;
+}
+
+/* keygen_rns after its samplers, bfv_keygen.cuh:129-145 */
+int mi355ntt_bfv_keygen(const mi355ntt_bfv* b, mi355ntt_u64* d_secret_key, mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
+                        mi355ntt_stream stream)
+{
+    if (!b || !d_secret_key || !d_public_key || !d_e) return MI355NTT_EINVAL;
+    const unsigned R = b->p.R;
+    const size_t half = (size_t)R * b->p.n;
+    BFV_RC(mi355ntt_forward_batch(b->ntt, d_secret_key, R, R, stream));                                    /* :129 */
+    BFV_RC(mi355ntt_pointwise_mul(b->ntt, d_public_key, d_public_key + half, d_secret_key, R, R, stream)); /* :131-132 */
+    BFV_RC(mi355ntt_inverse_batch(b->ntt, d_public_key, R, R, stream));                                    /* :133 */
+    BFV_HIP(bfv_add_negate(b->p, b->d, d_public_key, d_e, (hipStream_t)stream));                           /* :144 */
+    return mi355ntt_forward_batch(b->ntt, d_public_key, R, R, stream);                                     /* :145 */
+}
+
+/* encryption_rns after its samplers, bfv_encryption.cuh:268-289 */
+int mi355ntt_bfv_encrypt(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
+                         const mi355ntt_u64* d_m, mi355ntt_stream stream)
+{
+    if (!b || !d_c || !d_public_key || !d_e || !d_m) return MI355NTT_EINVAL;
+    const unsigned R = b->p.R;
+    BFV_RC(mi355ntt_polymul_batch(b->ntt, d_c, d_public_key, 2 * R, R, stream));                           /* :268-271 */
+    BFV_HIP(bfv_encrypt_tail(b->p, b->d, d_c, d_e, d_m, (hipStream_t)stream));                             /* :278-289 */
+    return MI355NTT_OK;
+}
+
+/* decryption_rns, bfv_decryption.cuh:98-137; the plaintext lands at d_c + n (r - 1), r = num_primes - 1 */
+int mi355ntt_bfv_decrypt(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355ntt_u64* d_secret_key, mi355ntt_stream stream)
+{
+    if (!b || !d_c || !d_secret_key) return MI355NTT_EINVAL;
+    const unsigned R = b->p.R, r = b->p.r;
+    BFV_RC(mi355ntt_polymul_batch(b->ntt, d_c + (size_t)R * b->p.n, d_secret_key, r, R, stream));          /* :98-101 */
+    BFV_HIP(bfv_decrypt_scale(b->p, b->d, d_c, (hipStream_t)stream));                                      /* :103-121 */
+    BFV_HIP(bfv_decrypt_round(b->p, b->d, d_c, (hipStream_t)stream));                                      /* :126-137 */
+    return MI355NTT_OK;
+}
+
+}  // extern "C"

@@ -578,7 +578,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
             constexpr int r1 = r0 | (1 << j);
             u64 U = v[r0];
             if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
-            if constexpr (EX || NEAR) {
+            if constexpr (EX || NEAR || LOGN != 15) {   // (smaller n: the extra live value costs a wave of occupancy)
                 const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
                 v[r0] = U + Tm;
                 v[r1] = U + cq - Tm;

@@ -42,6 +42,13 @@ _SIGNATURES = {
     "mi355ntt_ctx_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, ctypes.c_int]),
     "mi355ntt_ctx_create_ex": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, ctypes.c_int, ctypes.c_uint]),
     "mi355ntt_ctx_uses_literal_kernels": (ctypes.c_int, [vp]),
+    "mi355ntt_bfv_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, u64, u64, ctypes.c_int, ctypes.c_uint]),
+    "mi355ntt_bfv_destroy": (ctypes.c_int, [vp]),
+    "mi355ntt_bfv_ntt": (vp, [vp]),
+    "mi355ntt_bfv_constants": (ctypes.c_int, [vp, u64p, u64p, u64p, u64p, u64p, u64p, u64p]),
+    "mi355ntt_bfv_keygen": (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    "mi355ntt_bfv_encrypt": (ctypes.c_int, [vp, vp, vp, vp, vp, vp]),
+    "mi355ntt_bfv_decrypt": (ctypes.c_int, [vp, vp, vp, vp]),
     "mi355ntt_ctx_destroy": (ctypes.c_int, [vp]),
     "mi355ntt_ctx_n": (ctypes.c_uint, [vp]),
     "mi355ntt_ctx_num_primes": (ctypes.c_uint, [vp]),

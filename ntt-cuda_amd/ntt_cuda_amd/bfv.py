@@ -25,3 +25,64 @@ def decryption_ntt(ctx, c, secret_key, n, q_amount, stream=None):
     """bfv_decryption.cuh:98-101: c1 = c[(r+1) n :], num = r, division = r + 1"""
     c1 = c.reshape(-1)[(q_amount + 1) * n:]
     ctx.polymul_batch(c1, secret_key, q_amount, q_amount + 1, stream)
+
+
+class BFVContext:
+    """The BFV launch layer on the GPU (C ABI section "BFV" of include/mi355ntt.h): parameter bootstrap of
+    demo.cu:62-272 and keygen_rns / encryption_rns / decryption_rns after their samplers.  `q`, `psi` list all primes,
+    the special one (dropped by encryption) last."""
+
+    def __init__(self, n, q, psi, t, gamma, device=0, exact_on_inexact_primes=False):
+        import ctypes
+        import numpy as np
+        from . import lib, _check, _np_u64, u64p, vp, CTX_EXACT_ON_INEXACT_PRIMES
+        self._h = vp()
+        qs, ps = _np_u64(np.atleast_1d(q)), _np_u64(np.atleast_1d(psi))
+        assert qs.size == ps.size
+        _check(lib().mi355ntt_bfv_create(ctypes.byref(self._h), int(n), int(qs.size), qs.ctypes.data_as(u64p),
+                                         ps.ctypes.data_as(u64p), int(t), int(gamma), int(device),
+                                         CTX_EXACT_ON_INEXACT_PRIMES if exact_on_inexact_primes else 0), "mi355ntt_bfv_create")
+        self.n, self.num_primes, self.t, self.gamma = int(n), int(qs.size), int(t), int(gamma)
+
+    def close(self):
+        from . import lib, vp
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mi355ntt_bfv_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_literal_kernels(self):
+        from . import lib
+        return bool(lib().mi355ntt_ctx_uses_literal_kernels(lib().mi355ntt_bfv_ntt(self._h)))
+
+    def constants(self):
+        import numpy as np
+        from . import lib, _check, u64p
+        r = self.num_primes - 1
+        out = dict(inv_punctured_q=np.zeros(r, np.uint64), neg_inv_q_mod_t_gamma=np.zeros(2, np.uint64),
+                   prod_t_gamma_mod_q=np.zeros(r, np.uint64), inv_q_last_mod_q=np.zeros(r, np.uint64),
+                   qi_div_t=np.zeros(r + 1, np.uint64), base_change_matrix=np.zeros(2 * r, np.uint64), mu_gamma=np.zeros(1, np.uint64))
+        _check(lib().mi355ntt_bfv_constants(self._h, *[v.ctypes.data_as(u64p) for v in out.values()]), "mi355ntt_bfv_constants")
+        out["mu_gamma"] = int(out["mu_gamma"][0])
+        return out
+
+    def keygen(self, secret_key, public_key, e, stream=None):
+        from . import lib, _check, _ptr, _stream
+        _check(lib().mi355ntt_bfv_keygen(self._h, _ptr(secret_key), _ptr(public_key), _ptr(e), _stream(stream)), "mi355ntt_bfv_keygen")
+
+    def encrypt(self, c, public_key, e, m, stream=None):
+        from . import lib, _check, _ptr, _stream
+        _check(lib().mi355ntt_bfv_encrypt(self._h, _ptr(c), _ptr(public_key), _ptr(e), _ptr(m), _stream(stream)), "mi355ntt_bfv_encrypt")
+
+    def decrypt(self, c, secret_key, stream=None):
+        """In place on c; returns the view of c holding the plaintext (c + n (num_primes - 2))."""
+        from . import lib, _check, _ptr, _stream
+        _check(lib().mi355ntt_bfv_decrypt(self._h, _ptr(c), _ptr(secret_key), _stream(stream)), "mi355ntt_bfv_decrypt")
+        off = self.n * (self.num_primes - 2)
+        return c.reshape(-1)[off: off + self.n]

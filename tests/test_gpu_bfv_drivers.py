@@ -1,0 +1,118 @@
+"""GPU: the BFV launch layer -- bootstrap constants, keygen_rns / encryption_rns /
+decryption_rns after their samplers -- against the oracle's literal restatement and the reference's known-answer test."""
+import os
+
+import numpy as np
+import pytest
+
+import params as P
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat1_decryption_n4096.npz")
+
+
+def demo_moduli(n, count):
+    """the reference's 55-bit demo moduli (demo.cu:35-36) with psi lowered to the 2n-th root for ring degree n"""
+    qs = P.Q55[:count]
+    return qs, [pow(psi, 32768 // n, q) for psi, q in zip(P.PSI55, qs)]
+
+
+@pytest.mark.gpu
+def test_bootstrap_constants_match_oracle(native, oracle, gpu):
+    """demo.cu:62-272 on the host vs the oracle restatement (itself pinned on the reference's constants in
+    tests/test_oracle_golden.py), for the KAT-1 moduli and the 55-bit demo moduli"""
+    from ntt_cuda_amd import bfv
+    z = np.load(GOLD)
+    for n, qs, psis, t, gamma in [(int(z["n"]), [int(x) for x in z["q"]], [int(x) for x in z["psi"]], int(z["t"]), int(z["gamma"])),
+                                  (32768, P.Q55, P.PSI55, 1024, P.GAMMA61)]:
+        want = oracle.bfv_constants(qs, psis, t, gamma)
+        ctx = bfv.BFVContext(n, qs, psis, t, gamma)
+        got = ctx.constants()
+        for key in ("inv_punctured_q", "neg_inv_q_mod_t_gamma", "prod_t_gamma_mod_q", "inv_q_last_mod_q", "qi_div_t"):
+            assert np.array_equal(got[key], want[key]), key
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_decryption_replays_reference_kat(native, oracle, gpu):
+    """decryption_test.cu:348,355: the embedded ciphertext decrypts to m[i] = i % 10, and every word the reference's
+    decryption_rns leaves in c is reproduced (oracle = literal restatement of all its kernels)."""
+    import torch
+    from ntt_cuda_amd import bfv
+    z = np.load(GOLD)
+    n = int(z["n"])
+    qs, psis = [int(x) for x in z["q"]], [int(x) for x in z["psi"]]
+    ctx = bfv.BFVContext(n, qs, psis, int(z["t"]), int(z["gamma"]))
+    assert ctx.uses_literal_kernels                  # the second KAT modulus is Barrett-inexact (test_barrett_exactness.py)
+    c = native.to_device(z["c_host"])
+    sk = native.to_device(z["sk_host"])
+    m = ctx.decrypt(c, sk)
+    torch.cuda.synchronize()
+    assert np.array_equal(native.to_host(m), np.arange(n, dtype=np.uint64) % 10)
+    want_c = z["c_host"].copy()
+    oracle.lib().orc_bfv_decrypt(oracle._p(want_c), oracle._p(z["sk_host"]), oracle._p(np.array(qs, np.uint64)), oracle._p(np.array(psis, np.uint64)),
+                                 len(qs), n, int(z["t"]), int(z["gamma"]), oracle._p(np.empty(n, np.uint64)), None)
+    assert np.array_equal(native.to_host(c), want_c)
+    ctx.close()
+    # the exact kernels decrypt the same ciphertext to the same plaintext
+    ctx = bfv.BFVContext(n, qs, psis, int(z["t"]), int(z["gamma"]), exact_on_inexact_primes=True)
+    c = native.to_device(z["c_host"])
+    assert np.array_equal(native.to_host(ctx.decrypt(c, sk)), np.arange(n, dtype=np.uint64) % 10)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,count", [(4096, 3), (32768, 4)])
+def test_keygen_encrypt_decrypt_match_oracle_and_round_trip(native, oracle, gpu, n, count):
+    """Same sampled inputs through the GPU drivers and the oracle: every output word equal; and the message comes back
+    (demo.cu:302-311)."""
+    import torch
+    from ntt_cuda_amd import bfv
+    qs, psis = demo_moduli(n, count)
+    t, gamma = 1024, P.GAMMA61
+    R = len(qs)
+    ctx = bfv.BFVContext(n, qs, psis, t, gamma)
+    assert not ctx.uses_literal_kernels
+    smp = oracle.bfv_sample(qs, n, 11)
+    pk = np.zeros((2, R, n), dtype=np.uint64)
+    pk[1] = smp["uniform"]
+    e_k = smp["err"]()
+    want_sk, want_pk = oracle.bfv_keygen_core(smp["ternary"], pk, e_k, qs, psis, n)
+    d_sk, d_pk = native.to_device(smp["ternary"]), native.to_device(pk)
+    ctx.keygen(d_sk, d_pk, native.to_device(e_k))
+    torch.cuda.synchronize()
+    assert np.array_equal(native.to_host(d_sk).reshape(R, n), want_sk)
+    assert np.array_equal(native.to_host(d_pk).reshape(2, R, n), want_pk)
+
+    m = smp["rng"].integers(0, t, size=n, dtype=np.uint64)
+    u = oracle.bfv_sample(qs, n, 111)["ternary"]
+    e = np.stack([smp["err"](), smp["err"]()])
+    c0 = np.stack([u, u])
+    want_c = oracle.bfv_encrypt_core(c0, want_pk, e, m, qs, psis, n, t)
+    d_c = native.to_device(c0)
+    ctx.encrypt(d_c, d_pk, native.to_device(e), native.to_device(m))
+    torch.cuda.synchronize()
+    assert np.array_equal(native.to_host(d_c).reshape(2, R, n), want_c.reshape(2, R, n))
+
+    want_after = want_c.reshape(-1).copy()
+    want_m = np.empty(n, np.uint64)
+    oracle.lib().orc_bfv_decrypt(oracle._p(want_after), oracle._p(np.ascontiguousarray(want_sk.reshape(-1)[: (R - 1) * n])),
+                                 oracle._p(np.array(qs, np.uint64)), oracle._p(np.array(psis, np.uint64)), R, n, t, gamma,
+                                 oracle._p(want_m), None)
+    got_m = ctx.decrypt(d_c, d_sk)
+    torch.cuda.synchronize()
+    assert np.array_equal(native.to_host(got_m), m) and np.array_equal(want_m, m)
+    assert np.array_equal(native.to_host(d_c).reshape(-1), want_after)
+    ctx.close()
+
+
+def test_bfv_create_rejects_unsupported_parameters(native):
+    """host-side validation happens before any GPU call"""
+    import ctypes
+    L = native.lib()
+    h = native.vp()
+    qs, psis = demo_moduli(4096, 3)
+    a = lambda v: np.array(v, np.uint64).ctypes.data_as(native.u64p)
+    assert L.mi355ntt_bfv_create(ctypes.byref(h), 4096, 3, a(qs), a(psis), 1000, P.GAMMA61, 0, 0) == native.EUNSUPPORTED   # t not 2^k
+    assert L.mi355ntt_bfv_create(ctypes.byref(h), 4096, 1, a(qs), a(psis), 1024, P.GAMMA61, 0, 0) == native.EUNSUPPORTED   # no special prime
+    assert L.mi355ntt_bfv_create(ctypes.byref(h), 4096, 3, a(qs), a(psis), 1024, 1 << 61, 0, 0) == native.EUNSUPPORTED     # gamma even
+    assert L.mi355ntt_bfv_create(ctypes.byref(h), 4096, 3, a(qs), a(psis), 1 << 20, P.GAMMA61, 0, 0) == native.EPARAM      # q != 1 mod t
