@@ -114,10 +114,11 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, u32 bytes)
     const u32 lo = __builtin_amdgcn_readfirstlane(lo32(b)), hi = __builtin_amdgcn_readfirstlane(hi32(b));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((u64)hi << 32) | lo), 0, bytes, 0x00020000);
 }
-// Cache policy of the polynomial stream (aux bits of the buffer instructions: 2 = nt).  Every coefficient is read once
-// and written once per launch, the twiddle tables are re-read by every workgroup: keep the stream from evicting them.
+// Cache policy of the polynomial stream (aux bits of the buffer instructions: 2 = nt).  Measured (tools/memsys_experiments.sh):
+// nt loads are within noise on the forward kernel and cost the inverse 4-5 % at 4096 polynomials, nt stores cost 3-7 %
+// everywhere -- the default policy stays.
 #ifndef MI355NTT_STREAM_AUX_LD
-#define MI355NTT_STREAM_AUX_LD 2
+#define MI355NTT_STREAM_AUX_LD 0
 #endif
 #ifndef MI355NTT_STREAM_AUX_ST
 #define MI355NTT_STREAM_AUX_ST 0
