@@ -526,6 +526,21 @@ constexpr int SCHED_GROUP = MI355NTT_SCHED_GROUP;
 // k-th register index (k = 0..15) whose bit j is clear
 __host__ __device__ constexpr int low_reg(int j, int k) { return ((k >> j) << (j + 1)) | (k & ((1 << j) - 1)); }
 
+// Twiddle ring of a round: GROUP butterflies per scheduling group, DEPTH buffers (the loads run DEPTH - 1 groups ahead).
+// VGPRs = 4 * GROUP * DEPTH.  The round at bit 0 reads lane-distinct entries that come from L2: smaller groups and a
+// deeper ring buy prefetch distance for the same registers.
+#ifndef MI355NTT_RING_GROUP_B0
+#define MI355NTT_RING_GROUP_B0 SCHED_GROUP
+#endif
+#ifndef MI355NTT_RING_DEPTH_B0
+#define MI355NTT_RING_DEPTH_B0 2
+#endif
+template <int LOGN, int B>
+struct Ring {
+    static constexpr int GROUP = (B == 0 && LOGN == 15) ? MI355NTT_RING_GROUP_B0 : SCHED_GROUP;
+    static constexpr int DEPTH = (B == 0 && LOGN == 15) ? MI355NTT_RING_DEPTH_B0 : 2;
+};
+
 // Twiddles of butterfly group G of a round (GROUP butterflies per group, 16 / GROUP groups per stage).
 // FWD: stages run j = JA, JA-1, ...; INV: j = JA, JA+1, ...
 template <int LOGN, int B, int JA, bool FWD, int GROUP, int G>
@@ -560,18 +575,22 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
 {
     constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
     constexpr bool EX = Lazy<HL>::EXACT;
-    constexpr int GROUP = SCHED_GROUP, GPS = 16 / GROUP, NG = (JHI + 1) * GPS;
-    constexpr bool VEC = (B != Geo<LOGN>::B0);              // twiddles arrive in VGPRs: software-pipeline them one group ahead
+    constexpr bool VEC = (B != Geo<LOGN>::B0);              // twiddles arrive in VGPRs: software-pipelined DEPTH - 1 groups ahead
+    constexpr int GROUP = Ring<LOGN, B>::GROUP, DEPTH = Ring<LOGN, B>::DEPTH, GPS = 16 / GROUP, NG = (JHI + 1) * GPS;
     const u64 cq = (u64)Lazy<HL>::TQ * p.q;
     const unsigned thi = t >> B;
-    TwPair Wc[GROUP], Wn[GROUP];
-    load_tw_group<LOGN, B, JHI, true, GROUP, 0>(Wc, tw, twr, thi);
+    TwPair W[DEPTH][GROUP];
+    static_for<DEPTH - 1>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d < NG) load_tw_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi);
+    });
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int j = JHI - g / GPS;
         constexpr int s = LOGN - 1 - (B + j);
         constexpr bool red = (RMASK >> s) & 1u;
-        if constexpr (g + 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + 1>(Wn, tw, twr, thi);
+        TwPair (&Wc)[GROUP] = W[g % DEPTH];
+        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -592,7 +611,6 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
 #endif
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (g + 1 < NG) static_for<GROUP>([&](auto kc) { Wc[decltype(kc)::value] = Wn[decltype(kc)::value]; });
     });
 }
 
@@ -602,14 +620,14 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
 {
     constexpr InvPolicy<LOGN, HL> POL{};
     constexpr bool EX = Lazy<HL>::EXACT;
-#ifndef MI355NTT_GS_GROUP_B0
-#define MI355NTT_GS_GROUP_B0 SCHED_GROUP
-#endif
-    constexpr int GROUP = (B == 0) ? MI355NTT_GS_GROUP_B0 : SCHED_GROUP, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
+    constexpr int GROUP = Ring<LOGN, B>::GROUP, DEPTH = Ring<LOGN, B>::DEPTH, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
     constexpr bool VEC = (B != Geo<LOGN>::B0);
     const unsigned thi = t >> B;
-    TwPair Wc[GROUP], Wn[GROUP];
-    load_tw_group<LOGN, B, JLO, false, GROUP, 0>(Wc, tw, twr, thi);
+    TwPair W[DEPTH][GROUP];
+    static_for<DEPTH - 1>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d < NG) load_tw_group<LOGN, B, JLO, false, GROUP, d>(W[d], tw, twr, thi);
+    });
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int j = JLO + g / GPS;
@@ -617,7 +635,8 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
         constexpr bool last = (beta == LOGN - 1);
         constexpr bool red = (POL.mask >> beta) & 1u;
         const u64 cq = (u64)POL.cmul[beta] * p.q;
-        if constexpr (g + 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + 1>(Wn, tw, twr, thi);
+        TwPair (&Wc)[GROUP] = W[g % DEPTH];
+        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -640,7 +659,6 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
 #endif
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (g + 1 < NG) static_for<GROUP>([&](auto kc) { Wc[decltype(kc)::value] = Wn[decltype(kc)::value]; });
     });
 }
 
