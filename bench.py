@@ -28,6 +28,16 @@ for _p in (os.path.join(ROOT, "ntt-cuda_amd"), os.path.join(ROOT, "oracle")):
 # BASELINE configs 2-4: the four largest 60-bit primes = 1 mod 2^16, minimal 2n-th roots
 Q60 = [1152921504606584833, 1152921504598720513, 1152921504597016577, 1152921504595968001]
 PSI60 = [4443670208963, 100545759574150, 31693996050849, 88651361085495]
+# BASELINE configs[4] (BFV at n = 2^15, 4 x 60-bit RNS): the special prime that encryption drops = the next 60-bit prime
+# = 1 mod 2^16 below Q60[3], with its minimal primitive 2n-th root; t and gamma as demo.cu:28,93
+Q60_SPECIAL, PSI60_SPECIAL = 1152921504595640321, 9679305630873
+BFV_T, BFV_GAMMA = 1024, 2305843009213683713
+# the reference's published BFV configuration (Article.pdf p26 Table 7: n = 32768, log q = 880, r = 16): demo.cu:35-36
+DEMO_Q16 = [18014398506729473, 36028797017456641, 36028797014704129, 36028797014573057, 36028797014376449, 36028797013327873,
+            36028797013000193, 36028797012606977, 36028797010444289, 36028797009985537, 36028797005856769, 36028797005529089,
+            36028797005135873, 36028797003694081, 36028797003563009, 36028797001138177]
+DEMO_PSI16 = [58232959302, 1155186985540, 631260524634, 1526647220035, 455957817523, 1650884166641, 10316746886, 768741990072,
+              3911086673862, 5947090524825, 47595902954, 2691682578057, 3903338373, 235185854118, 1769787302793, 3151164484090]
 HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_TRANSFORM = 2 * 32768 * 8   # one in-place transform reads and writes the polynomial once
 
@@ -113,6 +123,88 @@ def cpu_baseline(n, qs, psis):
             "sample": "%d polys (n=%d, %d primes) x %d passes, OpenMP over polynomials, %.1f s wall; host has %d logical CPUs; "
                       "rates by thread count: %s" % (best[2], n, len(qs), best[3], best[4], cores,
                                                      ", ".join("%d: %.0f" % (k, v) for k, v in sorted(tried.items())))}
+
+
+def bfv_round_trip(torch, ntt, n, dev, with_cpu, qs, psis, label):
+    """keygen + encrypt + decrypt after the samplers (SURVEY.md 8f row 1) on the GPU, sampled polynomials as inputs;
+    the CPU figure is the oracle's literal restatement, one thread (SEAL is not in this image)."""
+    from ntt_cuda_amd import bfv
+    R = len(qs)
+    ctx = bfv.BFVContext(n, qs, psis, BFV_T, BFV_GAMMA, device=dev.index or 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    qcol = torch.tensor(qs, dtype=torch.int64, device=dev).unsqueeze(1)
+
+    def residues(x):                       # [n] small signed -> [R][n] residues
+        return torch.where(x.unsqueeze(0) < 0, qcol + x.unsqueeze(0), x.unsqueeze(0).expand(R, n)).contiguous()
+
+    def ternary():
+        return residues(torch.randint(-1, 2, (n,), dtype=torch.int64, device=dev, generator=g))
+
+    def err():
+        return residues(torch.round(torch.randn(n, device=dev, generator=g) * 3.2).to(torch.int64))
+
+    sk0, e_k = ternary(), err()
+    pk0 = torch.zeros(2, R, n, dtype=torch.int64, device=dev)
+    pk0[1] = synth(torch, R, n, qs, dev, seed=6)
+    u, e2 = ternary(), torch.stack([err(), err()])
+    c0 = torch.stack([u, u]).contiguous()
+    m = torch.randint(0, BFV_T, (n,), dtype=torch.int64, device=dev, generator=g)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps=20):
+        tot = 0.0
+        for i in range(reps + 3):
+            args_ = fn(None)
+            torch.cuda.synchronize()
+            e0.record()
+            fn(args_)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                tot += e0.elapsed_time(e1)
+        return tot / reps * 1e3, args_
+
+    def keygen(a):
+        if a is None:
+            return (sk0.clone(), pk0.clone())
+        ctx.keygen(a[0], a[1], e_k)
+
+    keygen_us, (sk, pk) = timed(keygen)
+
+    def encrypt(a):
+        if a is None:
+            return (c0.clone(),)
+        ctx.encrypt(a[0], pk, e2, m)
+
+    encrypt_us, (c,) = timed(encrypt)
+    c_keep = c.clone()
+
+    def decrypt(a):
+        if a is None:
+            return (c_keep.clone(),)
+        ctx.decrypt(a[0], sk)
+
+    decrypt_us, (cd,) = timed(decrypt)
+    off = n * (R - 2)
+    assert torch.equal(cd.reshape(-1)[off: off + n], m), "BFV round trip failed"
+    out = {"workload": "n=%d, %s, t=%d, 61-bit gamma; drivers after the samplers, one ciphertext" % (n, label, BFV_T),
+           "keygen_us": keygen_us, "encrypt_us": encrypt_us, "decrypt_us": decrypt_us, "round_trip_ok": True}
+    if with_cpu:
+        import numpy as np
+        import oracle_py as oracle
+        h = lambda x: ntt.to_host(x)
+        t0 = time.perf_counter()
+        sk_o, pk_o = oracle.bfv_keygen_core(h(sk0), h(pk0), h(e_k), qs, psis, n)
+        t1 = time.perf_counter()
+        c_o = oracle.bfv_encrypt_core(h(c0), pk_o, h(e2), h(m), qs, psis, n, BFV_T)
+        t2 = time.perf_counter()
+        m_o = oracle.bfv_decrypt(c_o.reshape(-1), sk_o.reshape(-1)[: (R - 1) * n], qs, psis, n, BFV_T, BFV_GAMMA)
+        t3 = time.perf_counter()
+        assert np.array_equal(m_o, h(m)) and np.array_equal(c_o.reshape(-1), h(c_keep).reshape(-1))
+        out["cpu_oracle_1thread_us"] = {"keygen": (t1 - t0) * 1e6, "encrypt": (t2 - t1) * 1e6, "decrypt": (t3 - t2) * 1e6,
+                                        "note": "literal restatement incl. table construction per call; same words as the GPU"}
+    ctx.close()
+    return out
 
 
 def main():
@@ -259,7 +351,13 @@ def main():
         out["extras"] = {"config2_fused_polymul_batch256_per_s": 256 / (mul_ms * 1e-3), "config2_fused_polymul_ms": mul_ms,
                          "config1_batch1_fwd_inv_pair_us": pair_us, "config1_batch1_forward_us": fwd_us,
                          "config1_batch1_inverse_us": inv_us,
-                         "reference_published_v100_us": {"forward": 39, "inverse": 23, "source": "Article.pdf p25 Table 6 (55-bit q)"}}
+                         "reference_published_v100_us": {"forward": 39, "inverse": 23, "source": "Article.pdf p25 Table 6 (55-bit q)"},
+                         "config4_bfv": bfv_round_trip(torch, ntt, n, dev, not args.no_cpu_baseline, Q60 + [Q60_SPECIAL],
+                                                       PSI60 + [PSI60_SPECIAL], "4 x 60-bit RNS + special prime"),
+                         "bfv_reference_demo_16_primes": dict(
+                             bfv_round_trip(torch, ntt, n, dev, False, DEMO_Q16, DEMO_PSI16, "the 16 primes of demo.cu:35-36 (log q = 880)"),
+                             reference_published_v100_us={"keygen": 427.81, "encrypt": 514.73, "decrypt": 246.48, "includes": "samplers",
+                                                          "source": "Article.pdf p26 Table 7"})}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, Q60, PSI60)
     elif rank == 0:

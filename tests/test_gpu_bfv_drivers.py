@@ -61,13 +61,16 @@ def test_decryption_replays_reference_kat(native, oracle, gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,count", [(4096, 3), (32768, 4)])
+@pytest.mark.parametrize("n,count", [(4096, 3), (32768, 4), (32768, 60)])
 def test_keygen_encrypt_decrypt_match_oracle_and_round_trip(native, oracle, gpu, n, count):
     """Same sampled inputs through the GPU drivers and the oracle: every output word equal; and the message comes back
     (demo.cu:302-311)."""
     import torch
     from ntt_cuda_amd import bfv
-    qs, psis = demo_moduli(n, count)
+    if count == 60:      # BASELINE configs[4]: four 60-bit primes + the special one
+        qs, psis = P.Q60 + [P.Q60_SPECIAL], P.PSI60 + [P.PSI60_SPECIAL]
+    else:
+        qs, psis = demo_moduli(n, count)
     t, gamma = 1024, P.GAMMA61
     R = len(qs)
     ctx = bfv.BFVContext(n, qs, psis, t, gamma)
