@@ -187,6 +187,28 @@ int mi355ntt_bfv_encrypt(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355
  * d_c is overwritten exactly as the reference overwrites it; the plaintext is at d_c + n * (num_primes - 2). */
 int mi355ntt_bfv_decrypt(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_secret_key, mi355ntt_stream stream);
 
+/* ---- samplers and the complete drivers --------------------------------------------------
+ * generate_random / generate_random_default (distributions.cuh:192-276): Salsa20/20 keystream, floor(nbytes / 64)
+ * blocks written to d_out (16-byte aligned), 64-bit nonce, block counter from 0.  The reference uses key = 32 x 0x01
+ * (_default) or 32 x 77, nonce 0 -- the same stream on every call; pass a fresh nonce per call for anything real. */
+int mi355ntt_salsa20_keystream(void* d_out, size_t nbytes, const unsigned char* key32, mi355ntt_u64 nonce, mi355ntt_stream stream);
+/* bytes of keystream keygen_rns / encryption_rns consume (bfv_keygen.cuh:99, bfv_encryption.cuh:228) */
+size_t mi355ntt_bfv_keygen_random_bytes(const mi355ntt_bfv* bfv);
+size_t mi355ntt_bfv_encrypt_random_bytes(const mi355ntt_bfv* bfv);
+/* ternary_dist_xq + uniform_dist_xq + gaussian_dist_xq (bfv_keygen.cuh:14-79): random bytes -> ternary secret key,
+ * uniform second half of the public key, error polynomial d_temp.  The integer conversions are the reference's words;
+ * the Gaussian one calls the device normcdfinvf (CUDA's is not specified to the ulp): same distribution. */
+int mi355ntt_bfv_sample_keygen(const mi355ntt_bfv* bfv, const void* d_in, mi355ntt_u64* d_secret_key, mi355ntt_u64* d_public_key,
+                               mi355ntt_u64* d_temp, mi355ntt_stream stream);
+/* convert_ternary_gaussian_x2 (bfv_encryption.cuh:17-109): random bytes -> u in both halves of d_c, e0 | e1 in d_e */
+int mi355ntt_bfv_sample_encrypt(const mi355ntt_bfv* bfv, const void* d_in, mi355ntt_u64* d_c, mi355ntt_u64* d_e, mi355ntt_stream stream);
+/* keygen_rns (bfv_keygen.cuh:95-151) and encryption_rns (bfv_encryption.cuh:223-290) complete: keystream with the
+ * reference's default key into the caller's d_in (sizes above), samplers, then the drivers declared earlier */
+int mi355ntt_bfv_keygen_rns(const mi355ntt_bfv* bfv, void* d_in, mi355ntt_u64* d_secret_key, mi355ntt_u64* d_public_key,
+                            mi355ntt_u64* d_temp, mi355ntt_u64 nonce, mi355ntt_stream stream);
+int mi355ntt_bfv_encryption_rns(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, void* d_in,
+                                mi355ntt_u64* d_e, const mi355ntt_u64* d_m, mi355ntt_u64 nonce, mi355ntt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,4 +69,20 @@ inline int decryption_rns(const mi355ntt_bfv* bfv, unsigned long long* c, const 
     return mi355ntt_bfv_decrypt(bfv, c, secret_key, stream);
 }
 
+// ---- the complete drivers, samplers included: `in` is the caller's random-byte buffer as in the reference
+// (mi355ntt_bfv_keygen_random_bytes / _encrypt_random_bytes give the sizes the drivers consume); `nonce` = 0 reproduces
+// the reference's fixed keystream (generate_random_default) ----
+inline int keygen_rns(const mi355ntt_bfv* bfv, unsigned char* in, unsigned long long* secret_key, unsigned long long* public_key,
+                      unsigned long long* temp, mi355ntt_stream stream, unsigned long long nonce = 0)
+{
+    return mi355ntt_bfv_keygen_rns(bfv, in, secret_key, public_key, temp, nonce, stream);
+}
+
+inline int encryption_rns(const mi355ntt_bfv* bfv, unsigned long long* c, const unsigned long long* public_key, unsigned char* in,
+                          unsigned long long* e, const unsigned long long* m_poly_device, mi355ntt_stream stream,
+                          unsigned long long nonce = 0)
+{
+    return mi355ntt_bfv_encryption_rns(bfv, c, public_key, in, e, m_poly_device, nonce, stream);
+}
+
 }  // namespace mi355

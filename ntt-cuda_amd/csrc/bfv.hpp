@@ -39,6 +39,18 @@ struct BfvDevice {
     const u64* d_base_change = nullptr;  // [2][r]
 };
 
+// ---- samplers ----
+struct BfvSalsaKey {
+    unsigned k[8];            // the 32 key bytes as little-endian words
+};
+// generate_random / generate_random_default (distributions.cuh:192-276): Salsa20/20 keystream into d_out, floor(nbytes / 64) blocks
+hipError_t bfv_salsa20_keystream(void* d_out, size_t nbytes, const BfvSalsaKey& key, u64 nonce, hipStream_t s);
+// ternary_dist_xq, uniform_dist_xq, gaussian_dist_xq (bfv_keygen.cuh:14-79, call sites :112-114) in one pass
+hipError_t bfv_sample_keygen(const BfvParams& p, const BfvDevice& d, const unsigned char* in, u64* secret_key, u64* public_key,
+                             u64* temp, hipStream_t s);
+// convert_ternary_gaussian_x2 (bfv_encryption.cuh:17-109)
+hipError_t bfv_sample_encrypt(const BfvParams& p, const BfvDevice& d, const unsigned char* in, u64* c, u64* e, hipStream_t s);
+
 // poly_add_negate_xq (bfv_keygen.cuh:80-93) on [R][n]
 hipError_t bfv_add_negate(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* e, hipStream_t s);
 // poly_add_xq + divide_and_round_q_last_inplace_add_x2 + divide_and_round_q_last_inplace_loop_xq + weird_m_stuff

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstring>
 #include <new>
 
@@ -197,6 +198,69 @@ int mi355ntt_bfv_decrypt(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355nt
     BFV_HIP(bfv_decrypt_scale(b->p, b->d, d_c, (hipStream_t)stream));                                      /* :103-121 */
     BFV_HIP(bfv_decrypt_round(b->p, b->d, d_c, (hipStream_t)stream));                                      /* :126-137 */
     return MI355NTT_OK;
+}
+
+/* ---------------- samplers and the complete drivers ---------------- */
+
+static BfvSalsaKey salsa_key(const unsigned char* key32)
+{
+    BfvSalsaKey k;
+    for (int i = 0; i < 8; i++)
+        k.k[i] = (unsigned)key32[4 * i] | ((unsigned)key32[4 * i + 1] << 8) | ((unsigned)key32[4 * i + 2] << 16) | ((unsigned)key32[4 * i + 3] << 24);
+    return k;
+}
+
+int mi355ntt_salsa20_keystream(void* d_out, size_t nbytes, const unsigned char* key32, mi355ntt_u64 nonce, mi355ntt_stream stream)
+{
+    if (!d_out || !key32) return MI355NTT_EINVAL;
+    if (((uintptr_t)d_out & 15) != 0) return MI355NTT_EINVAL;
+    BFV_HIP(bfv_salsa20_keystream(d_out, nbytes, salsa_key(key32), nonce, (hipStream_t)stream));
+    return MI355NTT_OK;
+}
+
+size_t mi355ntt_bfv_keygen_random_bytes(const mi355ntt_bfv* b)
+{
+    return b ? (size_t)9 * b->p.R * b->p.n + (size_t)4 * b->p.n : 0;      /* bfv_keygen.cuh:99 */
+}
+
+size_t mi355ntt_bfv_encrypt_random_bytes(const mi355ntt_bfv* b)
+{
+    return b ? (size_t)b->p.n + (size_t)8 * b->p.n : 0;                   /* bfv_encryption.cuh:228 */
+}
+
+int mi355ntt_bfv_sample_keygen(const mi355ntt_bfv* b, const void* d_in, mi355ntt_u64* d_secret_key, mi355ntt_u64* d_public_key,
+                               mi355ntt_u64* d_temp, mi355ntt_stream stream)
+{
+    if (!b || !d_in || !d_secret_key || !d_public_key || !d_temp) return MI355NTT_EINVAL;
+    BFV_HIP(bfv_sample_keygen(b->p, b->d, static_cast<const unsigned char*>(d_in), d_secret_key, d_public_key, d_temp, (hipStream_t)stream));
+    return MI355NTT_OK;
+}
+
+int mi355ntt_bfv_sample_encrypt(const mi355ntt_bfv* b, const void* d_in, mi355ntt_u64* d_c, mi355ntt_u64* d_e, mi355ntt_stream stream)
+{
+    if (!b || !d_in || !d_c || !d_e) return MI355NTT_EINVAL;
+    BFV_HIP(bfv_sample_encrypt(b->p, b->d, static_cast<const unsigned char*>(d_in), d_c, d_e, (hipStream_t)stream));
+    return MI355NTT_OK;
+}
+
+static const unsigned char kDefaultKey[32] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};   /* memset(k, 1, 32), distributions.cuh:236 */
+
+int mi355ntt_bfv_keygen_rns(const mi355ntt_bfv* b, void* d_in, mi355ntt_u64* d_secret_key, mi355ntt_u64* d_public_key,
+                            mi355ntt_u64* d_temp, mi355ntt_u64 nonce, mi355ntt_stream stream)
+{
+    if (!b) return MI355NTT_EINVAL;
+    BFV_RC(mi355ntt_salsa20_keystream(d_in, mi355ntt_bfv_keygen_random_bytes(b), kDefaultKey, nonce, stream));   /* :99  */
+    BFV_RC(mi355ntt_bfv_sample_keygen(b, d_in, d_secret_key, d_public_key, d_temp, stream));                      /* :112-114 */
+    return mi355ntt_bfv_keygen(b, d_secret_key, d_public_key, d_temp, stream);                                    /* :129-145 */
+}
+
+int mi355ntt_bfv_encryption_rns(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, void* d_in,
+                                mi355ntt_u64* d_e, const mi355ntt_u64* d_m, mi355ntt_u64 nonce, mi355ntt_stream stream)
+{
+    if (!b) return MI355NTT_EINVAL;
+    BFV_RC(mi355ntt_salsa20_keystream(d_in, mi355ntt_bfv_encrypt_random_bytes(b), kDefaultKey, nonce, stream));   /* :228 */
+    BFV_RC(mi355ntt_bfv_sample_encrypt(b, d_in, d_c, d_e, stream));                                               /* :246 */
+    return mi355ntt_bfv_encrypt(b, d_c, d_public_key, d_e, d_m, stream);                                          /* :268-289 */
 }
 
 }  // extern "C"

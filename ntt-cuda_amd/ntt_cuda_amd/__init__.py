@@ -49,6 +49,13 @@ _SIGNATURES = {
     "mi355ntt_bfv_keygen": (ctypes.c_int, [vp, vp, vp, vp, vp]),
     "mi355ntt_bfv_encrypt": (ctypes.c_int, [vp, vp, vp, vp, vp, vp]),
     "mi355ntt_bfv_decrypt": (ctypes.c_int, [vp, vp, vp, vp]),
+    "mi355ntt_salsa20_keystream": (ctypes.c_int, [vp, ctypes.c_size_t, ctypes.c_char_p, u64, vp]),
+    "mi355ntt_bfv_keygen_random_bytes": (ctypes.c_size_t, [vp]),
+    "mi355ntt_bfv_encrypt_random_bytes": (ctypes.c_size_t, [vp]),
+    "mi355ntt_bfv_sample_keygen": (ctypes.c_int, [vp, vp, vp, vp, vp, vp]),
+    "mi355ntt_bfv_sample_encrypt": (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    "mi355ntt_bfv_keygen_rns": (ctypes.c_int, [vp, vp, vp, vp, vp, u64, vp]),
+    "mi355ntt_bfv_encryption_rns": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, u64, vp]),
     "mi355ntt_ctx_destroy": (ctypes.c_int, [vp]),
     "mi355ntt_ctx_n": (ctypes.c_uint, [vp]),
     "mi355ntt_ctx_num_primes": (ctypes.c_uint, [vp]),
@@ -131,6 +138,18 @@ def _ptr(t):
         return vp(t)
     assert t.is_cuda and t.is_contiguous() and t.element_size() == 8, "need a contiguous 64-bit CUDA tensor"
     return vp(t.data_ptr())
+
+
+def _byte_ptr(t):
+    assert t.is_cuda and t.is_contiguous() and t.element_size() == 1, "need a contiguous byte CUDA tensor"
+    return vp(t.data_ptr())
+
+
+def salsa20_keystream(out, key32, nonce=0, stream=None):
+    """generate_random / generate_random_default (distributions.cuh:192-276): fills the byte tensor `out` (whole 64-byte
+    blocks) with the Salsa20/20 keystream of (key32, 64-bit nonce), block counter from 0."""
+    assert len(key32) == 32
+    _check(lib().mi355ntt_salsa20_keystream(_byte_ptr(out), out.numel(), bytes(key32), int(nonce), _stream(stream)), "mi355ntt_salsa20_keystream")
 
 
 def _stream(stream=None):

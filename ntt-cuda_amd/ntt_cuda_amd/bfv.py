@@ -86,3 +86,35 @@ class BFVContext:
         _check(lib().mi355ntt_bfv_decrypt(self._h, _ptr(c), _ptr(secret_key), _stream(stream)), "mi355ntt_bfv_decrypt")
         off = self.n * (self.num_primes - 2)
         return c.reshape(-1)[off: off + self.n]
+
+    # ---- samplers and the complete drivers
+    @property
+    def keygen_random_bytes(self):
+        from . import lib
+        return int(lib().mi355ntt_bfv_keygen_random_bytes(self._h))
+
+    @property
+    def encrypt_random_bytes(self):
+        from . import lib
+        return int(lib().mi355ntt_bfv_encrypt_random_bytes(self._h))
+
+    def sample_keygen(self, rnd, secret_key, public_key, temp, stream=None):
+        from . import lib, _check, _ptr, _byte_ptr, _stream
+        _check(lib().mi355ntt_bfv_sample_keygen(self._h, _byte_ptr(rnd), _ptr(secret_key), _ptr(public_key), _ptr(temp), _stream(stream)),
+               "mi355ntt_bfv_sample_keygen")
+
+    def sample_encrypt(self, rnd, c, e, stream=None):
+        from . import lib, _check, _ptr, _byte_ptr, _stream
+        _check(lib().mi355ntt_bfv_sample_encrypt(self._h, _byte_ptr(rnd), _ptr(c), _ptr(e), _stream(stream)), "mi355ntt_bfv_sample_encrypt")
+
+    def keygen_rns(self, rnd, secret_key, public_key, temp, nonce=0, stream=None):
+        """keygen_rns complete (bfv_keygen.cuh:95-151): keystream (reference default key) -> samplers -> key generation"""
+        from . import lib, _check, _ptr, _byte_ptr, _stream
+        _check(lib().mi355ntt_bfv_keygen_rns(self._h, _byte_ptr(rnd), _ptr(secret_key), _ptr(public_key), _ptr(temp), int(nonce),
+                                             _stream(stream)), "mi355ntt_bfv_keygen_rns")
+
+    def encryption_rns(self, c, public_key, rnd, e, m, nonce=0, stream=None):
+        """encryption_rns complete (bfv_encryption.cuh:223-290)"""
+        from . import lib, _check, _ptr, _byte_ptr, _stream
+        _check(lib().mi355ntt_bfv_encryption_rns(self._h, _ptr(c), _ptr(public_key), _byte_ptr(rnd), _ptr(e), _ptr(m), int(nonce),
+                                                 _stream(stream)), "mi355ntt_bfv_encryption_rns")

@@ -439,6 +439,128 @@ int orc_bfv_encrypt_core(u64* c, const u64* public_key, const u64* e, const u64*
     return 0;
 }
 
+/* ------------------------------------------------------------------ samplers */
+
+/* VecCrypt with blks_per_chunk = 1 over an all-zero buffer (distributions.cuh:48-155, generate_random_default :249-276):
+ * Salsa20/20 keystream, "expand 32-byte k", 64-bit nonce, block counter = block index.  Pinned by the ECRYPT
+ * Salsa20/20 256-bit known-answer vector (tests/test_samplers.py). */
+static uint32_t rotl32(uint32_t u, int c) { return (u << c) | (u >> (32 - c)); }
+static uint32_t load_le32(const unsigned char* x)
+{
+    return (uint32_t)x[0] | ((uint32_t)x[1] << 8) | ((uint32_t)x[2] << 16) | ((uint32_t)x[3] << 24);
+}
+void orc_salsa20_keystream(unsigned char* out, unsigned long nblocks, const unsigned char* key, u64 nonce)
+{
+    static const unsigned char sigma[17] = "expand 32-byte k";
+    for (unsigned long blockno = 0; blockno < nblocks; blockno++) {
+        uint32_t j[16], x[16];
+        j[0] = load_le32(sigma + 0);  j[1] = load_le32(key + 0);   j[2] = load_le32(key + 4);   j[3] = load_le32(key + 8);
+        j[4] = load_le32(key + 12);   j[5] = load_le32(sigma + 4); j[6] = (uint32_t)nonce;      j[7] = (uint32_t)(nonce >> 32);
+        j[8] = (uint32_t)blockno;     j[9] = (uint32_t)((u64)blockno >> 32);
+        j[10] = load_le32(sigma + 8); j[11] = load_le32(key + 16); j[12] = load_le32(key + 20); j[13] = load_le32(key + 24);
+        j[14] = load_le32(key + 28);  j[15] = load_le32(sigma + 12);
+        for (int i = 0; i < 16; i++) x[i] = j[i];
+        for (int i = 20; i > 0; i -= 2) {                                          /* ROUNDS = 20, salsa_common.h:14 */
+            x[4] ^= rotl32(x[0] + x[12], 7);   x[8] ^= rotl32(x[4] + x[0], 9);    x[12] ^= rotl32(x[8] + x[4], 13);   x[0] ^= rotl32(x[12] + x[8], 18);
+            x[9] ^= rotl32(x[5] + x[1], 7);    x[13] ^= rotl32(x[9] + x[5], 9);   x[1] ^= rotl32(x[13] + x[9], 13);   x[5] ^= rotl32(x[1] + x[13], 18);
+            x[14] ^= rotl32(x[10] + x[6], 7);  x[2] ^= rotl32(x[14] + x[10], 9);  x[6] ^= rotl32(x[2] + x[14], 13);   x[10] ^= rotl32(x[6] + x[2], 18);
+            x[3] ^= rotl32(x[15] + x[11], 7);  x[7] ^= rotl32(x[3] + x[15], 9);   x[11] ^= rotl32(x[7] + x[3], 13);   x[15] ^= rotl32(x[11] + x[7], 18);
+            x[1] ^= rotl32(x[0] + x[3], 7);    x[2] ^= rotl32(x[1] + x[0], 9);    x[3] ^= rotl32(x[2] + x[1], 13);    x[0] ^= rotl32(x[3] + x[2], 18);
+            x[6] ^= rotl32(x[5] + x[4], 7);    x[7] ^= rotl32(x[6] + x[5], 9);    x[4] ^= rotl32(x[7] + x[6], 13);    x[5] ^= rotl32(x[4] + x[7], 18);
+            x[11] ^= rotl32(x[10] + x[9], 7);  x[8] ^= rotl32(x[11] + x[10], 9);  x[9] ^= rotl32(x[8] + x[11], 13);   x[10] ^= rotl32(x[9] + x[8], 18);
+            x[12] ^= rotl32(x[15] + x[14], 7); x[13] ^= rotl32(x[12] + x[15], 9); x[14] ^= rotl32(x[13] + x[12], 13); x[15] ^= rotl32(x[14] + x[13], 18);
+        }
+        for (int i = 0; i < 16; i++) {
+            uint32_t v = x[i] + j[i];
+            unsigned char* o = out + blockno * 64 + 4 * i;
+            o[0] = (unsigned char)v; o[1] = (unsigned char)(v >> 8); o[2] = (unsigned char)(v >> 16); o[3] = (unsigned char)(v >> 24);
+        }
+    }
+}
+
+/* ternary_dist_xq (bfv_keygen.cuh:14-31) / first half of convert_ternary_gaussian_x2 (bfv_encryption.cuh:17-45):
+ * the SAME n bytes for every prime; note byte 255 yields the value 2 */
+void orc_sample_ternary_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs)
+{
+    for (size_t i = 0; i < (size_t)n * q_amount; i++) {
+        float d = (float)in[i % n];
+        d /= (255.0f / 3);
+        int b = (int)d - 1;
+        out[i] = (u64)(b < 0) * qs[i / n] + (u64)(long long)b;
+    }
+}
+
+/* uniform_dist_xq (bfv_keygen.cuh:33-45): one 64-bit word per coefficient per prime */
+void orc_sample_uniform_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs)
+{
+    for (size_t i = 0; i < (size_t)n * q_amount; i++) {
+        u64 w;
+        memcpy(&w, in + 8 * i, 8);
+        double d = (double)w;
+        d /= (double)18446744073709551615ULL;          /* UINT64_MAX converts to 2^64 */
+        d *= (double)(qs[i / n] - 1);
+        out[i] = (u64)d;
+    }
+}
+
+/* Inverse normal CDF for the Gaussian sampler's restatement.  The reference calls CUDA's normcdfinvf, whose last-ulp
+ * behaviour is not specified: this (Wichura AS241, double precision, rounded to float) agrees with any faithful
+ * implementation except where d * 3.2 lands within an ulp of an integer -- the Gaussian path is compared
+ * statistically and by mismatch rate, not bit for bit. */
+static double as241(double p)
+{
+    static const double a[8] = {3.3871328727963666080e0, 1.3314166789178437745e2, 1.9715909503065514427e3, 1.3731693765509461125e4,
+                                4.5921953931549871457e4, 6.7265770927008700853e4, 3.3430575583588128105e4, 2.5090809287301226727e3};
+    static const double b[8] = {1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3, 2.1213794301586595867e4,
+                                3.9307895800092710610e4, 2.8729085735721942674e4, 5.2264952788528545610e3};
+    static const double c[8] = {1.42343711074968357734e0, 4.63033784615654529590e0, 5.76949722146069140550e0, 3.64784832476320460504e0,
+                                1.27045825245236838258e0, 2.41780725177450611770e-1, 2.27238449892691845833e-2, 7.74545014278341407640e-4};
+    static const double d[8] = {1.0, 2.05319162663775882187e0, 1.67638483018380384940e0, 6.89767334985100004550e-1, 1.48103976427480074590e-1,
+                                1.51986665636164571966e-2, 5.47593808499534494600e-4, 1.05075007164441684324e-9};
+    static const double e[8] = {6.65790464350110377720e0, 5.46378491116411436990e0, 1.78482653991729133580e0, 2.96560571828504891230e-1,
+                                2.65321895265761230930e-2, 1.24266094738807843860e-3, 2.71155556874348757815e-5, 2.01033439929228813265e-7};
+    static const double f[8] = {1.0, 5.99832206555887937690e-1, 1.36929880922735805310e-1, 1.48753612908506148525e-2, 7.86869131145613259100e-4,
+                                1.84631831751005468180e-5, 1.42151175831644588870e-7, 2.04426310338993978564e-15};
+    double q = p - 0.5, r, val;
+    if (fabs(q) <= 0.425) {
+        r = 0.180625 - q * q;
+        return q * (((((((a[7] * r + a[6]) * r + a[5]) * r + a[4]) * r + a[3]) * r + a[2]) * r + a[1]) * r + a[0]) /
+               (((((((b[7] * r + b[6]) * r + b[5]) * r + b[4]) * r + b[3]) * r + b[2]) * r + b[1]) * r + b[0]);
+    }
+    r = q < 0 ? p : 1.0 - p;
+    r = sqrt(-log(r));
+    if (r <= 5.0) {
+        r -= 1.6;
+        val = (((((((c[7] * r + c[6]) * r + c[5]) * r + c[4]) * r + c[3]) * r + c[2]) * r + c[1]) * r + c[0]) /
+              (((((((d[7] * r + d[6]) * r + d[5]) * r + d[4]) * r + d[3]) * r + d[2]) * r + d[1]) * r + d[0]);
+    } else {
+        r -= 5.0;
+        val = (((((((e[7] * r + e[6]) * r + e[5]) * r + e[4]) * r + e[3]) * r + e[2]) * r + e[1]) * r + e[0]) /
+              (((((((f[7] * r + f[6]) * r + f[5]) * r + f[4]) * r + f[3]) * r + f[2]) * r + f[1]) * r + f[0]);
+    }
+    return q < 0 ? -val : val;
+}
+
+/* gaussian_dist_xq (bfv_keygen.cuh:47-79) / the two Gaussian halves of convert_ternary_gaussian_x2: the SAME n 32-bit
+ * words for every prime; stdev 3.2, mean 0 (salsa_common.h:31-32), clamp +-19.2, truncation toward zero */
+void orc_sample_gaussian_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs)
+{
+    for (size_t i = 0; i < (size_t)n * q_amount; i++) {
+        uint32_t w;
+        memcpy(&w, in + 4 * (i % n), 4);
+        float d = (float)w;
+        d /= 4294967295.0f;
+        if (d == 0) d += 1.192092896e-07F;
+        else if (d == 1) d -= 1.192092896e-07F;
+        d = (float)as241((double)d);
+        d = d * (float)3.2 + 0;
+        if (d > 19.2) d = 19.2;
+        else if (d < -19.2) d = -19.2;
+        int dd = (int)d;
+        out[i] = dd < 0 ? qs[i / n] + (u64)(long long)dd : (u64)dd;
+    }
+}
+
 /* -------------------------------------------------------- synthetic inputs */
 
 /* splitmix64, state x0 = seed, value = z mod q */

@@ -76,6 +76,14 @@ int orc_bfv_keygen_core(u64* secret_key, u64* public_key, const u64* e, const u6
 int orc_bfv_encrypt_core(u64* c, const u64* public_key, const u64* e, const u64* m, const u64* qs, const u64* psis,
                          unsigned r_plus_1, unsigned n, u64 t);
 
+/* ---- samplers: Salsa20/20 keystream as generate_random_default produces it (distributions.cuh:48-155,
+ * 249-276) and the merged conversion kernels (bfv_keygen.cuh:14-79, bfv_encryption.cuh:17-109).  The integer paths are
+ * bit-exact restatements; the Gaussian one uses its own inverse normal CDF (CUDA's normcdfinvf is not specified to the ulp). */
+void orc_salsa20_keystream(unsigned char* out, unsigned long nblocks, const unsigned char* key, u64 nonce);
+void orc_sample_ternary_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs);
+void orc_sample_uniform_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs);
+void orc_sample_gaussian_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs);
+
 /* constants the bootstrap derives, exposed for the known-answer checks
  * (old/decryption.cu:46,97,103,113; old/encryption.cu:98,101) */
 void orc_bfv_constants(const u64* qs, const u64* psis, unsigned r_plus_1, u64 t, u64 gamma,

@@ -74,6 +74,12 @@ def lib():
         L.orc_bfv_keygen_core.argtypes = [u64p, u64p, u64p, u64p, u64p, ctypes.c_uint, ctypes.c_uint]
         L.orc_bfv_encrypt_core.restype = ctypes.c_int
         L.orc_bfv_encrypt_core.argtypes = [u64p, u64p, u64p, u64p, u64p, u64p, ctypes.c_uint, ctypes.c_uint, u64]
+        u8p = ctypes.POINTER(ctypes.c_ubyte)
+        L.orc_salsa20_keystream.restype = None
+        L.orc_salsa20_keystream.argtypes = [u8p, ctypes.c_ulong, u8p, u64]
+        for nm in ("orc_sample_ternary_xq", "orc_sample_uniform_xq", "orc_sample_gaussian_xq"):
+            getattr(L, nm).restype = None
+            getattr(L, nm).argtypes = [u8p, u64p, ctypes.c_uint, ctypes.c_uint, u64p]
         L.orc_bfv_constants.restype = None
         L.orc_bfv_constants.argtypes = [u64p, u64p, ctypes.c_uint, u64, u64, u64p, u64p, u64p, u64p, u64p, u64p]
         L.orc_splitmix_fill.restype = None
@@ -227,6 +233,28 @@ def bfv_sample(qs, n, seed):
         return [np.rint(rng.normal(0, 3.2, size=n)).astype(np.int64) for _ in range(count)]
     uniform = np.stack([rng.integers(0, q, size=n, dtype=np.uint64) for q in qs])
     return dict(ternary=residues(tern), err=lambda: residues(err(1)[0]), uniform=uniform, rng=rng)
+
+
+def _p8(a):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))
+
+
+def salsa20_keystream(nbytes, key32, nonce=0):
+    """generate_random(_default) over a zeroed buffer (distributions.cuh:192-276): floor(nbytes/64) blocks"""
+    out = np.zeros(nbytes // 64 * 64, dtype=np.uint8)
+    key = np.frombuffer(bytes(key32), dtype=np.uint8).copy()
+    lib().orc_salsa20_keystream(_p8(out), nbytes // 64, _p8(key), int(nonce))
+    return out
+
+
+def sample_xq(kind, rnd, n, qs):
+    """ternary_dist_xq / uniform_dist_xq / gaussian_dist_xq on the byte array `rnd` (already offset as the caller wants)"""
+    qs = np.array(qs, dtype=np.uint64)
+    out = np.empty((len(qs), n), dtype=np.uint64)
+    rnd = np.ascontiguousarray(rnd, dtype=np.uint8)
+    getattr(lib(), "orc_sample_%s_xq" % kind)(_p8(rnd), _p(out), n, len(qs), _p(qs))
+    return out
 
 
 def bfv_constants(qs, psis, t, gamma):
