@@ -21,6 +21,11 @@ PSI60 = [4443670208963, 100545759574150, 31693996050849, 88651361085495]
 # BASELINE configs[4] (BFV, 4 x 60-bit RNS): the special prime encryption drops = next 60-bit prime = 1 mod 2^16 below Q60[3]
 Q60_SPECIAL, PSI60_SPECIAL = 1152921504595640321, 9679305630873
 
+# primes far from a power of two (q = 1 mod 2^16, minimal primitive 2^16-th roots): the kernels pick their partial
+# reduction and butterfly form by headroom class (64 - bit length) and by "near 2^k or not" -- these reach the general forms
+GENERAL_PRIMES = {57: (93674872251744257, 1408945640707), 59: (536108499642941441, 7338562720162),
+                  60: (818574268271493121, 19054799908346), 62: (3827699395296821249, 61619156825551)}
+
 # the reference's first four 55-bit demo primes, BFV_Scheme/demo.cu:35-36 (entries 1..4 of the 16-prime set)
 Q55 = [36028797017456641, 36028797014704129, 36028797014573057, 36028797014376449]
 PSI55 = [1155186985540, 631260524634, 1526647220035, 455957817523]

@@ -321,6 +321,86 @@ def test_persistent_loop_ragged_counts(native, oracle, gpu, num):
     ctx.close()
 
 
+KERNEL_FORMS = {
+    "hl6-near": (P.Q55, P.PSI55),
+    "hl6-general": ([P.GENERAL_PRIMES[57][0], P.Q55[0]], [P.GENERAL_PRIMES[57][1], P.PSI55[0]]),
+    "hl4-near": (P.Q60, P.PSI60),
+    "hl4-general": ([P.GENERAL_PRIMES[60][0], P.GENERAL_PRIMES[59][0], P.Q60[0]], [P.GENERAL_PRIMES[60][1], P.GENERAL_PRIMES[59][1], P.PSI60[0]]),
+    "hl2-near": ([P.EDGE_PRIMES[62][0], P.EDGE_PRIMES[61][0]], [P.EDGE_PRIMES[62][1][32768], P.EDGE_PRIMES[61][1][32768]]),
+    "hl2-general": ([P.GENERAL_PRIMES[62][0], P.Q60[1]], [P.GENERAL_PRIMES[62][1], P.PSI60[1]]),
+}
+
+
+@pytest.mark.parametrize("form", sorted(KERNEL_FORMS))
+@pytest.mark.parametrize("num", [7, 300])
+def test_every_kernel_form_at_n32768_matches_oracle(native, oracle, gpu, form, num):
+    """n = 2^15 has six instantiations per kernel (headroom class x near-2^k or general prime: partial reduction, exact or
+    approximate quotient, fused butterfly) on two paths (two-launch below 129 polynomials, persistent single-pass above):
+    every one of them against the oracle, with adversarial coefficients (0, 1, q-1, q-2) mixed into the random ones."""
+    import torch
+    n = 32768
+    qs, psis = KERNEL_FORMS[form]
+    Pn = len(qs)
+    for q in qs:
+        assert native.barrett_is_exact(q)
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    assert not ctx.uses_literal_kernels
+    a = oracle.synth_batch(n, num, qs, 31337).reshape(num, n)
+    b = oracle.synth_batch(n, num, qs, 555).reshape(num, n)
+    for y in range(min(num, 2 * Pn)):
+        q = qs[y % Pn]
+        a[y, :8] = [0, 1, q - 1, q - 2, q - 1, 0, q - 1, 1]
+        a[y, n - 4:] = [q - 1, q - 1, 0, q - 2]
+        a[y, 1000:1000 + 64] = q - 1
+    d_a, d_b = dev(native, a), dev(native, b)
+    ctx.forward_batch(d_a, num)
+    A = host(native, d_a).reshape(num, n)
+    sample = sorted(set(list(range(min(num, 2 * Pn))) + [num // 2, num - 2, num - 1] + ([255, 256, 257] if num > 257 else [])))
+    for y in sample:
+        assert np.array_equal(A[y], oracle.forward(a[y], prm, y % Pn)), (form, y)
+    ctx.forward_batch(d_b, num)
+    B = host(native, d_b).reshape(num, n)
+    ctx.inverse_batch(d_a, num)
+    assert np.array_equal(host(native, d_a).reshape(num, n), a)
+    d_f = dev(native, a)
+    ctx.polymul_batch(d_f, d_b, num)
+    F = host(native, d_f).reshape(num, n)
+    for y in sample:
+        one = oracle.Params(n, [qs[y % Pn]], [psis[y % Pn]], tables=False)
+        want = oracle.inverse(oracle.pointwise_batch(A[y], B[y], one).reshape(-1), prm, y % Pn)
+        assert np.array_equal(F[y], want), (form, y)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("form", sorted(KERNEL_FORMS))
+def test_every_headroom_class_at_small_n_matches_oracle(native, oracle, gpu, n, form):
+    """the n = 2^11..2^14 kernels are instantiated per headroom class as well: 55- to 62-bit moduli, near 2^k and general"""
+    qs, psis32k = KERNEL_FORMS[form]
+    psis = [pow(psi, 32768 // n, q) for psi, q in zip(psis32k, qs)]
+    Pn, num = len(qs), 3 * len(qs) + 2
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = oracle.synth_batch(n, num, qs, 99).reshape(num, n)
+    b = oracle.synth_batch(n, num, qs, 98).reshape(num, n)
+    for y in range(num):
+        q = qs[y % Pn]
+        a[y, :4] = [0, q - 1, q - 2, 1]
+        a[y, n // 2: n // 2 + 32] = q - 1
+    A, B = oracle.forward_batch(a, prm), oracle.forward_batch(b, prm)
+    d_a, d_b = dev(native, a), dev(native, b)
+    ctx.forward_batch(d_a, num)
+    assert np.array_equal(host(native, d_a).reshape(-1), A.reshape(-1))
+    ctx.forward_batch(d_b, num)
+    d_f = dev(native, a)
+    ctx.polymul_batch(d_f, d_b, num)
+    assert np.array_equal(host(native, d_f).reshape(-1), oracle.inverse_batch(oracle.pointwise_batch(A, B, prm), prm).reshape(-1))
+    ctx.inverse_batch(d_a, num)
+    assert np.array_equal(host(native, d_a).reshape(-1), a.reshape(-1))
+    ctx.close()
+
+
 def test_streams_are_respected(native, oracle, gpu):
     """All entry points are asynchronous on the caller's stream (the reference's batch launchers use stream 0)."""
     import torch
