@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time scatter -> forward+inverse -> gather from a rank-0-resident batch (SURVEY.md 8(e), report 2)")
     return ap.parse_args()
 
 
@@ -358,6 +360,37 @@ def main():
                              bfv_round_trip(torch, ntt, n, dev, False, DEMO_Q16, DEMO_PSI16, "the 16 primes of demo.cu:35-36 (log q = 880)"),
                              reference_published_v100_us={"keygen": 427.81, "encrypt": 514.73, "decrypt": 246.48, "includes": "samplers",
                                                           "source": "Article.pdf p26 Table 7"})}
+    if args.end_to_end:
+        # SURVEY.md 8(e) report 2: the batch lives on rank 0; chunked scatter / transform / gather (ntt_cuda_amd/shard.py)
+        try:
+            from ntt_cuda_amd import shard
+            total = world * batch
+            full = synth(torch, total, n, Q60, dev, seed=77) if rank == 0 else None
+            reps = max(1, args.steps // 20)
+
+            def tf(piece, count):
+                ctx.forward_batch(piece, count)
+                ctx.inverse_batch(piece, count)
+
+            if world == 1:
+                e2e = lambda: tf(full.clone(), total)
+            else:
+                e2e = lambda: shard.scatter_transform_gather(full, total, n, P, tf, chunks=4, src=0, device=dev)
+            e2e()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                e2e()
+            barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            out["end_to_end"] = {"pairs_per_s": total * reps / el, "ms_per_batch": el / reps * 1e3, "global_batch": total,
+                                 "what": "rank-0-resident batch: chunked scatter, forward+inverse per shard, gather back to rank 0"}
+        except Exception as exc:            # never let the optional leg break the contract line
+            out["end_to_end"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, Q60, PSI60)
     elif rank == 0:

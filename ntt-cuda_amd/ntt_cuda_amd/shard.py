@@ -79,3 +79,72 @@ def max_over_ranks(value, device=None, group=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def _pieces(count, division, chunks):
+    """split `count` polynomials into up to `chunks` contiguous pieces whose starts are multiples of `division`"""
+    groups, tail = divmod(count, division)
+    chunks = max(1, min(chunks, groups if groups else 1))
+    base, extra = divmod(groups, chunks)
+    out, g = [], 0
+    for c in range(chunks):
+        gc = base + (1 if c < extra else 0)
+        out.append([g * division, gc * division])
+        g += gc
+    out[-1][1] += tail
+    return [(s, c) for s, c in out if c]
+
+
+def scatter_transform_gather(full, num, n, division, transform, chunks=4, src=0, group=None, device=None, dtype=torch.int64):
+    """End to end from a root-held batch (report 2): root `src` deals the shards out in `chunks` pieces
+    per rank, every rank transforms piece k in place with `transform(piece_tensor, count)` while piece k + 1 is arriving
+    and piece k - 1 is on its way back, and `src` returns the assembled [num, n] result (other ranks None).
+
+    Pieces start at multiples of `division`, so `transform` sees polynomial y of a piece with prime y % division -- the
+    same call as on the whole batch.  At 8 GPUs the transfers dominate (256 MiB per peer over one xGMI link each way vs
+    < 1 ms of transforms), so this is what a caller with a host- or root-resident batch should expect; the compute-only
+    figure is bench.py's default."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    plan = {r: shard_range(num, division, r, world) for r in range(world)}
+    pieces = {r: [(plan[r][0] + s, c) for s, c in _pieces(plan[r][1], division, chunks)] if plan[r][1] else [] for r in range(world)}
+    depth = max(len(p) for p in pieces.values()) if pieces else 0
+    if rank == src:
+        full = full.reshape(num, n)
+        out = torch.empty_like(full)
+        for k in range(depth + 2):
+            ops = []
+            for r in range(world):                                   # piece k goes out, piece k - 2 comes back
+                if r == src:
+                    continue
+                if k < len(pieces[r]):
+                    s, c = pieces[r][k]
+                    ops.append(dist.P2POp(dist.isend, full[s:s + c].contiguous(), r, group))
+                if 0 <= k - 2 < len(pieces[r]):
+                    s, c = pieces[r][k - 2]
+                    ops.append(dist.P2POp(dist.irecv, out[s:s + c], r, group))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            if 0 <= k - 1 < len(pieces[src]):                        # the root's own piece k - 1 meanwhile
+                s, c = pieces[src][k - 1]
+                piece = full[s:s + c].clone()
+                transform(piece, c)
+                out[s:s + c] = piece
+            for q in reqs:
+                q.wait()
+        return out
+    mine = pieces[rank]
+    bufs = [torch.empty((c, n), dtype=dtype, device=device) for _, c in mine]
+    for k in range(depth + 2):
+        ops = []
+        if k < len(mine):
+            ops.append(dist.P2POp(dist.irecv, bufs[k], src, group))
+        if 0 <= k - 2 < len(mine):
+            ops.append(dist.P2POp(dist.isend, bufs[k - 2], src, group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        # piece k - 1 arrived in round k - 1 (waited for at the end of that round): transform it while k arrives and k - 2 leaves
+        if 0 <= k - 1 < len(mine):
+            transform(bufs[k - 1], mine[k - 1][1])
+            if bufs[k - 1].is_cuda:
+                torch.cuda.current_stream().synchronize()            # the result must be complete before round k + 1 sends it
+        for q in reqs:
+            q.wait()
+    return None

@@ -75,3 +75,50 @@ def test_scatter_transform_gather_world2(tmp_path, num):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_worker, args=(2, _free_port(), num, 4096, out), nprocs=2, join=True)
     assert np.load(out)[0] == 1
+
+
+def _worker_e2e(rank, world, port, num, n, chunks, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    for p in (os.path.join(root, "ntt-cuda_amd"), os.path.join(root, "oracle"), here):
+        sys.path.insert(0, p)
+    import oracle_py as oracle
+    from ntt_cuda_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    qs = [P.REF_PARAMS_4096_58BIT[0], P.REF_PARAMS[4096][0], P.EDGE_PRIMES[59][0]]
+    psis = [P.REF_PARAMS_4096_58BIT[1], P.REF_PARAMS[4096][1], P.EDGE_PRIMES[59][1][4096]]
+    prm = oracle.Params(n, qs, psis)
+    full = torch.from_numpy(oracle.synth_batch(n, num, qs, 3).view(np.int64)) if rank == 0 else None
+    calls = []
+
+    def transform(piece, count):                      # stands in for ctx.forward_batch(piece, count) on a GPU
+        calls.append(count)
+        res = oracle.forward_batch(piece.numpy().view(np.uint64), prm, division=len(qs)).reshape(count, n)
+        piece.copy_(torch.from_numpy(res.view(np.int64)))
+
+    got = shard.scatter_transform_gather(full, num, n, len(qs), transform, chunks=chunks, src=0)
+    assert sum(calls) == shard.shard_range(num, len(qs), rank, world)[1]
+    if rank == 0:
+        want = oracle.forward_batch(full.numpy().view(np.uint64), prm, division=len(qs)).reshape(num, n)
+        np.save(out, np.array([int(np.array_equal(got.numpy().view(np.uint64), want))]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num,chunks", [(24, 3), (7, 4), (2, 2)])
+def test_pipelined_scatter_transform_gather_world2(tmp_path, num, chunks):
+    """the chunked end-to-end pipeline (pieces in flight both ways while one is transformed) returns what one call on the
+    whole batch returns, also for ragged batches and when a rank gets nothing"""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker_e2e, args=(2, _free_port(), num, 4096, chunks, out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1
+
+
+def test_piece_plan():
+    from ntt_cuda_amd.shard import _pieces
+    for count, div, chunks in [(24, 3, 4), (7, 3, 4), (2, 3, 2), (1024, 4, 4), (5, 4, 8)]:
+        ps = _pieces(count, div, chunks)
+        assert sum(c for _, c in ps) == count and all(s % div == 0 for s, _ in ps)
+        assert [s for s, _ in ps] == sorted(s for s, _ in ps) and len(ps) <= chunks
