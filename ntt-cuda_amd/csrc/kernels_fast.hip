@@ -206,10 +206,7 @@ hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, 
     const TwPair* twf = reinterpret_cast<const TwPair*>(t.d_fwd);
     const TwPair* twi = reinterpret_cast<const TwPair*>(t.d_inv);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
-    // few polynomials at n = 2^15: a persistent workgroup would hold one CU per polynomial for the whole product; the
-    // three-step sequence spreads each transform over 16 CUs (latency path of the transforms, kernels_fast_impl.cuh)
-    const bool small15 = (t.log_n == 15 && num <= latency_path_max_polys());
-    switch (small15 ? 0u : t.log_n) {
+    switch (t.log_n) {   // (n = 2^15 switches to a three-launch latency path for few polynomials by itself: launch_mul)
     case 11: return fast_mul_11(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
     case 12: return fast_mul_12(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
     case 13: return fast_mul_13(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
