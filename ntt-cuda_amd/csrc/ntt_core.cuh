@@ -606,9 +606,6 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
                 v[r0] = U;
                 ct_bfly4(v[r0], v[r1], Wc[k].w, Wc[k].wp, p.nq, cq);
             }
-#ifdef MI355NTT_INNER_FENCE
-            if constexpr (VEC && ((k + 1) % MI355NTT_INNER_FENCE) == 0 && k + 1 < GROUP) __builtin_amdgcn_sched_barrier(0);
-#endif
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
     });
@@ -654,9 +651,6 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
                 v[r0] = S;
                 v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
             }
-#ifdef MI355NTT_INNER_FENCE
-            if constexpr (VEC && ((k + 1) % MI355NTT_INNER_FENCE) == 0 && k + 1 < GROUP) __builtin_amdgcn_sched_barrier(0);
-#endif
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
     });
