@@ -31,6 +31,7 @@ extern "C" {
 #endif
 
 typedef unsigned long long mi355ntt_u64;
+typedef unsigned int mi355ntt_u32;
 typedef struct mi355ntt_ctx mi355ntt_ctx;
 typedef void* mi355ntt_stream; /* hipStream_t */
 
@@ -153,6 +154,23 @@ int mi355ntt_barrett_raw(mi355ntt_u64* d_c, const mi355ntt_u64* d_a, const mi355
                          const unsigned* bit_length, mi355ntt_stream stream);     /* barrett*, poly_arithmetic.cuh:9-98 */
 int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_u64 q, mi355ntt_u64 mu,
                              int bit_length, mi355ntt_stream stream);                             /* barrett_int :100 */
+
+/* ------------------------------------------------------------------------------------------------
+ * The reference's 30-bit path (old/ntt_30bit.cuh): 32-bit words, q < 2^30, the caller's mu
+ * (floor(2^(2 bits) / q), old/30bit_ntt_test.cu:47-48) and 32-bit psi tables.  Same argument lists as the reference's
+ * launchers; the _batch_ forms take `num` polynomials of the same prime.  n in {2048 .. 32768}.
+ * ---------------------------------------------------------------------------------------------- */
+int mi355ntt_forward30_raw(mi355ntt_u32* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u32 q, mi355ntt_u32 mu, int bit_length,
+                           const mi355ntt_u32* d_psi_table);                                       /* forwardNTT, :321-359 */
+int mi355ntt_inverse30_raw(mi355ntt_u32* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u32 q, mi355ntt_u32 mu, int bit_length,
+                           const mi355ntt_u32* d_psiinv_table);                                    /* inverseNTT, :361-405 */
+int mi355ntt_forward30_batch_raw(mi355ntt_u32* d_a, unsigned n, const mi355ntt_u32* d_psi_table, unsigned num, mi355ntt_u32 q,
+                                 mi355ntt_u32 mu, int bit_length, mi355ntt_stream stream);
+int mi355ntt_inverse30_batch_raw(mi355ntt_u32* d_a, unsigned n, const mi355ntt_u32* d_psiinv_table, unsigned num, mi355ntt_u32 q,
+                                 mi355ntt_u32 mu, int bit_length, mi355ntt_stream stream);
+/* barrett_30bit (:10-35): a[i] = a[i] * b[i] mod q over `count` words */
+int mi355ntt_barrett30_raw(mi355ntt_u32* d_a, const mi355ntt_u32* d_b, size_t count, mi355ntt_u32 q, mi355ntt_u32 mu, int bit_length,
+                           mi355ntt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BFV launch layer around the NTT path: the parameter bootstrap of demo.cu:62-272 and the

@@ -392,4 +392,55 @@ int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi35
     return MI355NTT_OK;
 }
 
+/* ---------------- the reference's 30-bit path (old/ntt_30bit.cuh) ---------------- */
+static int check30(const void* a, const void* tab, unsigned n, mi355ntt_u32 q, int bits)
+{
+    if (!a || !tab) return MI355NTT_EINVAL;
+    if (!is_pow2(n) || n < 2048 || n > 32768) return MI355NTT_EUNSUPPORTED;      /* forwardNTT dispatch, old/ntt_30bit.cuh:321-359 */
+    if (bits < 3 || bits > 30 || q < 3 || (q >> bits) != 0) return MI355NTT_EUNSUPPORTED;
+    return MI355NTT_OK;
+}
+
+int mi355ntt_forward30_batch_raw(mi355ntt_u32* d_a, unsigned n, const mi355ntt_u32* d_psi_table, unsigned num, mi355ntt_u32 q,
+                                 mi355ntt_u32 mu, int bits, mi355ntt_stream s)
+{
+    int rc = check30(d_a, d_psi_table, n, q, bits);
+    if (rc) return rc;
+    if (num == 0) return MI355NTT_OK;
+    HIP_TRY(ntt30_forward(d_a, n, d_psi_table, num, q, mu, bits, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+
+int mi355ntt_inverse30_batch_raw(mi355ntt_u32* d_a, unsigned n, const mi355ntt_u32* d_psiinv_table, unsigned num, mi355ntt_u32 q,
+                                 mi355ntt_u32 mu, int bits, mi355ntt_stream s)
+{
+    int rc = check30(d_a, d_psiinv_table, n, q, bits);
+    if (rc) return rc;
+    if (num == 0) return MI355NTT_OK;
+    HIP_TRY(ntt30_inverse(d_a, n, d_psiinv_table, num, q, mu, bits, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+
+int mi355ntt_forward30_raw(mi355ntt_u32* d_a, unsigned n, mi355ntt_stream s, mi355ntt_u32 q, mi355ntt_u32 mu, int bits,
+                           const mi355ntt_u32* d_psi_table)
+{
+    return mi355ntt_forward30_batch_raw(d_a, n, d_psi_table, 1, q, mu, bits, s);
+}
+
+int mi355ntt_inverse30_raw(mi355ntt_u32* d_a, unsigned n, mi355ntt_stream s, mi355ntt_u32 q, mi355ntt_u32 mu, int bits,
+                           const mi355ntt_u32* d_psiinv_table)
+{
+    return mi355ntt_inverse30_batch_raw(d_a, n, d_psiinv_table, 1, q, mu, bits, s);
+}
+
+int mi355ntt_barrett30_raw(mi355ntt_u32* d_a, const mi355ntt_u32* d_b, size_t count, mi355ntt_u32 q, mi355ntt_u32 mu, int bits,
+                           mi355ntt_stream s)
+{
+    if (!d_a || !d_b) return MI355NTT_EINVAL;
+    if (bits < 3 || bits > 30 || q < 3 || (q >> bits) != 0) return MI355NTT_EUNSUPPORTED;
+    if (count == 0) return MI355NTT_OK;
+    HIP_TRY(ntt30_barrett(d_a, d_b, count, q, mu, bits, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+
 }  // extern "C"

@@ -51,4 +51,9 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
                           hipStream_t s);
 hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s);
 
+// ---- the reference's 30-bit path (kernels_ntt30.hip): 32-bit words, single prime, `num` polynomials of n words ----
+hipError_t ntt30_forward(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s);
+hipError_t ntt30_inverse(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s);
+hipError_t ntt30_barrett(unsigned* d_a, const unsigned* d_b, size_t count, unsigned q, unsigned mu, int bits, hipStream_t s);
+
 }  // namespace mi355ntt

@@ -49,6 +49,11 @@ _SIGNATURES = {
     "mi355ntt_bfv_keygen": (ctypes.c_int, [vp, vp, vp, vp, vp]),
     "mi355ntt_bfv_encrypt": (ctypes.c_int, [vp, vp, vp, vp, vp, vp]),
     "mi355ntt_bfv_decrypt": (ctypes.c_int, [vp, vp, vp, vp]),
+    "mi355ntt_forward30_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, vp]),
+    "mi355ntt_inverse30_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, vp]),
+    "mi355ntt_forward30_batch_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, vp]),
+    "mi355ntt_inverse30_batch_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, vp]),
+    "mi355ntt_barrett30_raw": (ctypes.c_int, [vp, vp, ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, vp]),
     "mi355ntt_salsa20_keystream": (ctypes.c_int, [vp, ctypes.c_size_t, ctypes.c_char_p, u64, vp]),
     "mi355ntt_bfv_keygen_random_bytes": (ctypes.c_size_t, [vp]),
     "mi355ntt_bfv_encrypt_random_bytes": (ctypes.c_size_t, [vp]),
@@ -143,6 +148,27 @@ def _ptr(t):
 def _byte_ptr(t):
     assert t.is_cuda and t.is_contiguous() and t.element_size() == 1, "need a contiguous byte CUDA tensor"
     return vp(t.data_ptr())
+
+
+def _ptr32(t):
+    assert t.is_cuda and t.is_contiguous() and t.element_size() == 4, "need a contiguous 32-bit CUDA tensor"
+    return vp(t.data_ptr())
+
+
+# the reference's 30-bit path (old/ntt_30bit.cuh): int32 CUDA tensors holding the 32-bit words
+def forward30(a, n, q, mu, bit_length, psi_table, num=1, stream=None):
+    _check(lib().mi355ntt_forward30_batch_raw(_ptr32(a), int(n), _ptr32(psi_table), int(num), int(q), int(mu), int(bit_length),
+                                              _stream(stream)), "mi355ntt_forward30_batch_raw")
+
+
+def inverse30(a, n, q, mu, bit_length, psiinv_table, num=1, stream=None):
+    _check(lib().mi355ntt_inverse30_batch_raw(_ptr32(a), int(n), _ptr32(psiinv_table), int(num), int(q), int(mu), int(bit_length),
+                                              _stream(stream)), "mi355ntt_inverse30_batch_raw")
+
+
+def barrett30(a, b, q, mu, bit_length, stream=None):
+    _check(lib().mi355ntt_barrett30_raw(_ptr32(a), _ptr32(b), a.numel(), int(q), int(mu), int(bit_length), _stream(stream)),
+           "mi355ntt_barrett30_raw")
 
 
 def salsa20_keystream(out, key32, nonce=0, stream=None):

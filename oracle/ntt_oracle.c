@@ -561,6 +561,73 @@ void orc_sample_gaussian_xq(const unsigned char* in, u64* out, unsigned n, unsig
     }
 }
 
+/* ------------------------------------------------------------- 30-bit path */
+
+/* old/ntt_30bit.cuh: 32-bit words, 64-bit products; singleBarrett :52-68 on one machine word */
+static inline uint32_t barrett30(u64 a, uint32_t q, uint32_t mu, int qbit)
+{
+    u64 rx = a >> (qbit - 2);
+    rx *= mu;
+    rx >>= qbit + 2;
+    rx *= q;
+    a -= rx;
+    if (a >= q) a -= q;
+    return (uint32_t)a;
+}
+
+/* forwardNTT (:321-359): every launch is the stage butterfly of CTBasedNTTInner (:199-227), length = 1 .. n/2 */
+void orc30_forward(uint32_t* a, unsigned n, uint32_t q, uint32_t mu, int qbit, const uint32_t* psi_tab)
+{
+    for (unsigned length = 1; length < n; length *= 2) {
+        unsigned step = (n / length) / 2;
+        for (unsigned g = 0; g < n / 2; g++) {
+            unsigned psi_step = g / step, j = psi_step * step * 2 + g % step;
+            uint32_t psi = psi_tab[length + psi_step];
+            uint32_t U = a[j];
+            uint32_t V = barrett30((u64)a[j + step] * psi, q, mu, qbit);
+            uint32_t r = U + V;
+            r -= q * (r >= q);
+            a[j] = r;
+            U += q * (U < V);
+            a[j + step] = U - V;
+        }
+    }
+}
+
+/* inverseNTT (:361-405): GSBasedINTTInner (:229-267) with the halving, length = n/2 .. 1 */
+void orc30_inverse(uint32_t* a, unsigned n, uint32_t q, uint32_t mu, int qbit, const uint32_t* psiinv_tab)
+{
+    uint32_t q2 = (q + 1) >> 1;
+    for (unsigned length = n / 2; length >= 1; length /= 2) {
+        unsigned step = (n / length) / 2;
+        for (unsigned g = 0; g < n / 2; g++) {
+            unsigned psi_step = g / step, j = psi_step * step * 2 + g % step;
+            uint32_t psiinv = psiinv_tab[length + psi_step];
+            uint32_t U = a[j], V = a[j + step];
+            uint32_t r = U + V;
+            r -= q * (r >= q);
+            a[j] = (r >> 1) + q2 * (r & 1);
+            U += q * (U < V);
+            uint32_t d = barrett30((u64)(U - V) * psiinv, q, mu, qbit);
+            a[j + step] = (d >> 1) + q2 * (d & 1);
+        }
+    }
+}
+
+/* barrett_30bit (:10-35) */
+void orc30_pointwise(uint32_t* a, const uint32_t* b, unsigned long count, uint32_t q, uint32_t mu, int qbit)
+{
+    for (unsigned long i = 0; i < count; i++) {
+        u64 rc = (u64)a[i] * b[i];
+        u64 rx = rc >> (qbit - 2);
+        rx *= mu;
+        rx >>= qbit + 2;
+        rx *= q;
+        rc -= rx;
+        a[i] = rc < q ? (uint32_t)rc : (uint32_t)(rc - q);
+    }
+}
+
 /* -------------------------------------------------------- synthetic inputs */
 
 /* splitmix64, state x0 = seed, value = z mod q */

@@ -84,6 +84,12 @@ void orc_sample_ternary_xq(const unsigned char* in, u64* out, unsigned n, unsign
 void orc_sample_uniform_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs);
 void orc_sample_gaussian_xq(const unsigned char* in, u64* out, unsigned n, unsigned q_amount, const u64* qs);
 
+/* ---- the 30-bit path (old/ntt_30bit.cuh): 32-bit words, single prime.  Pinned by the parameter
+ * tuples of getParams30 (old/NTT/old_design/final/parameter.h:73-115) and the schoolbook product. */
+void orc30_forward(uint32_t* a, unsigned n, uint32_t q, uint32_t mu, int qbit, const uint32_t* psi_tab);
+void orc30_inverse(uint32_t* a, unsigned n, uint32_t q, uint32_t mu, int qbit, const uint32_t* psiinv_tab);
+void orc30_pointwise(uint32_t* a, const uint32_t* b, unsigned long count, uint32_t q, uint32_t mu, int qbit);
+
 /* constants the bootstrap derives, exposed for the known-answer checks
  * (old/decryption.cu:46,97,103,113; old/encryption.cu:98,101) */
 void orc_bfv_constants(const u64* qs, const u64* psis, unsigned r_plus_1, u64 t, u64 gamma,

@@ -80,6 +80,11 @@ def lib():
         for nm in ("orc_sample_ternary_xq", "orc_sample_uniform_xq", "orc_sample_gaussian_xq"):
             getattr(L, nm).restype = None
             getattr(L, nm).argtypes = [u8p, u64p, ctypes.c_uint, ctypes.c_uint, u64p]
+        for nm in ("orc30_forward", "orc30_inverse"):
+            getattr(L, nm).restype = None
+            getattr(L, nm).argtypes = [u32p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, u32p]
+        L.orc30_pointwise.restype = None
+        L.orc30_pointwise.argtypes = [u32p, u32p, ctypes.c_ulong, ctypes.c_uint, ctypes.c_uint, ctypes.c_int]
         L.orc_bfv_constants.restype = None
         L.orc_bfv_constants.argtypes = [u64p, u64p, ctypes.c_uint, u64, u64, u64p, u64p, u64p, u64p, u64p, u64p]
         L.orc_splitmix_fill.restype = None
@@ -255,6 +260,43 @@ def sample_xq(kind, rnd, n, qs):
     rnd = np.ascontiguousarray(rnd, dtype=np.uint8)
     getattr(lib(), "orc_sample_%s_xq" % kind)(_p8(rnd), _p(out), n, len(qs), _p(qs))
     return out
+
+
+class Params30:
+    """30-bit path (old/ntt_30bit.cuh): bit length, mu = floor(2^(2k)/q) (old/30bit_ntt_test.cu:46-48), 32-bit tables"""
+
+    def __init__(self, n, q, psi):
+        L = lib()
+        self.n, self.q, self.psi = int(n), int(q), int(psi)
+        self.k = int(L.orc_bit_length(self.q))
+        self.mu = (1 << (2 * self.k)) // self.q
+        self.psiinv = int(L.orc_modinv(self.psi, self.q))
+        t64 = np.empty(self.n, dtype=np.uint64)
+        L.orc_fill_table(self.psi, self.q, _p(t64), self.n)
+        self.psi_tab = t64.astype(np.uint32)
+        L.orc_fill_table(self.psiinv, self.q, _p(t64), self.n)
+        self.psiinv_tab = t64.astype(np.uint32)
+
+
+def forward30(a, prm):
+    a = np.ascontiguousarray(a, dtype=np.uint32).copy()
+    for row in a.reshape(-1, prm.n):
+        lib().orc30_forward(_p32(row), prm.n, prm.q, prm.mu, prm.k, _p32(prm.psi_tab))
+    return a
+
+
+def inverse30(a, prm):
+    a = np.ascontiguousarray(a, dtype=np.uint32).copy()
+    for row in a.reshape(-1, prm.n):
+        lib().orc30_inverse(_p32(row), prm.n, prm.q, prm.mu, prm.k, _p32(prm.psiinv_tab))
+    return a
+
+
+def pointwise30(a, b, prm):
+    a = np.ascontiguousarray(a, dtype=np.uint32).copy()
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    lib().orc30_pointwise(_p32(a.reshape(-1)), _p32(b.reshape(-1)), a.size, prm.q, prm.mu, prm.k)
+    return a
 
 
 def bfv_constants(qs, psis, t, gamma):

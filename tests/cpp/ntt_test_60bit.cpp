@@ -10,6 +10,7 @@
 #include "../../ntt-cuda_amd/compat/ntt_60bit.hpp"
 #include "../../ntt-cuda_amd/compat/poly_arithmetic.hpp"
 #include "../../ntt-cuda_amd/compat/bfv_launch.hpp"   // compile check of the BFV launch layer
+#include "../../ntt-cuda_amd/compat/ntt_30bit.hpp"    // ... and of the 30-bit launchers (overloads on unsigned*)
 #include "../../oracle/ntt_oracle.h"
 
 using namespace mi355;

@@ -1,0 +1,83 @@
+"""The reference's 30-bit path (old/ntt_30bit.cuh): 32-bit words, one prime."""
+import numpy as np
+import pytest
+
+# getParams30, old/NTT/old_design/final/parameter.h:73-115: n -> (q, psi, psiinv, ninv, q_bit)
+PARAMS30 = {
+    2048: (12931073, 3733, 10610200, 12924759, 24),
+    4096: (33538049, 2386, 26102329, 33529861, 25),
+    8192: (8716289, 1089, 8196033, 8715225, 24),
+    16384: (13664257, 273, 8959348, 13663423, 24),
+    32768: (19070977, 377, 16642842, 19070395, 25),
+}
+
+
+def exact_forward(a, q, psi, n):
+    lg = n.bit_length() - 1
+    tab = [pow(psi, int(format(i, "0%db" % lg)[::-1], 2), q) for i in range(n)]
+    a = [int(x) for x in a]
+    length = 1
+    while length < n:
+        step = n // (2 * length)
+        for p in range(length):
+            w = tab[length + p]
+            for j in range(2 * p * step, 2 * p * step + step):
+                u, v = a[j], a[j + step] * w % q
+                a[j], a[j + step] = (u + v) % q, (u - v) % q
+        length *= 2
+    return np.array(a, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("n", sorted(PARAMS30))
+def test_oracle30_is_pinned_on_reference_parameters(oracle, n):
+    q, psi, psiinv, ninv, bits = PARAMS30[n]
+    prm = oracle.Params30(n, q, psi)
+    assert (prm.k, prm.psiinv) == (bits, psiinv) and pow(n, -1, q) == ninv and pow(psi, n, q) == q - 1
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, q, size=n, dtype=np.uint32)
+    a[:4] = [0, 1, q - 1, q - 2]
+    A = oracle.forward30(a, prm)
+    if n <= 4096:
+        assert np.array_equal(A, exact_forward(a, q, psi, n))          # the transform the reference means
+    assert np.array_equal(oracle.inverse30(A, prm), a)                  # halving butterflies fold n^-1 in
+    if n == 2048:                                                       # 30bit_ntt_test.cu's check: schoolbook product
+        b = rng.integers(0, q, size=n, dtype=np.uint32)
+        c = oracle.inverse30(oracle.pointwise30(A, oracle.forward30(b, prm), prm), prm)
+        want = oracle.ref_polymul(a.astype(np.uint64), b.astype(np.uint64), q)
+        assert np.array_equal(c.astype(np.uint64), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", sorted(PARAMS30))
+def test_gpu_30bit_path_matches_oracle(native, oracle, gpu, n):
+    import torch
+    q, psi, _, _, bits = PARAMS30[n]
+    prm = oracle.Params30(n, q, psi)
+    num = 5
+    rng = np.random.default_rng(7 * n)
+    a = rng.integers(0, q, size=(num, n), dtype=np.uint32)
+    b = rng.integers(0, q, size=(num, n), dtype=np.uint32)
+    a[0, :4] = [0, 1, q - 1, q - 2]
+    dev32 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(gpu)
+    host32 = lambda t: t.cpu().numpy().view(np.uint32)
+    d_a, d_b = dev32(a), dev32(b)
+    d_psi, d_psiinv = dev32(prm.psi_tab), dev32(prm.psiinv_tab)
+    native.forward30(d_a, n, q, prm.mu, bits, d_psi, num)
+    native.forward30(d_b, n, q, prm.mu, bits, d_psi, num)
+    torch.cuda.synchronize()
+    A, B = oracle.forward30(a, prm), oracle.forward30(b, prm)
+    assert np.array_equal(host32(d_a), A) and np.array_equal(host32(d_b), B)
+    native.barrett30(d_a, d_b, q, prm.mu, bits)
+    AB = oracle.pointwise30(A, B, prm)
+    assert np.array_equal(host32(d_a), AB)
+    native.inverse30(d_a, n, q, prm.mu, bits, d_psiinv, num)
+    assert np.array_equal(host32(d_a), oracle.inverse30(AB, prm))
+    native.inverse30(d_b, n, q, prm.mu, bits, d_psiinv, num)
+    assert np.array_equal(host32(d_b), b)
+
+
+def test_30bit_entry_points_reject_bad_arguments(native):
+    L = native.lib()
+    assert L.mi355ntt_forward30_raw(None, 2048, None, 12931073, 21767333, 24, None) == native.EINVAL
+    assert L.mi355ntt_forward30_batch_raw(native.vp(16), 1000, native.vp(16), 1, 12931073, 21767333, 24, None) == native.EUNSUPPORTED
+    assert L.mi355ntt_barrett30_raw(native.vp(16), native.vp(16), 8, 1 << 31, 5, 31, None) == native.EUNSUPPORTED
