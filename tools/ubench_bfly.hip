@@ -230,17 +230,47 @@ __device__ __forceinline__ void bfly<11>(u64& x, u64& y, const Consts& c)
     y = D - X;
 }
 
-// 12: variant 1 with per-chain twiddles held in VGPRs (as rounds 2 and 3 of the kernels have them)
-template <>
-__device__ __forceinline__ void bfly<12>(u64& x, u64& y, const Consts& c)
+// 12/13: variant 1 on 8 chains with the twiddle pair in SGPRs (as round 1 of the kernels has it) vs in per-chain VGPRs
+// (rounds 2 and 3): same instruction count, different operand sources
+template <bool VTW>
+__global__ void __launch_bounds__(1024) k_bfly_tw(unsigned long long* out, const Consts* cp, int iters)
 {
-    u64 w = c.w ^ (x & 0), wp = c.wp;
-    u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
-    u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
-    u64 T = y * w + h * c.nq;
-    u64 U = x;
-    x = U + T;
-    y = U + c.fourq - T;
+    __shared__ unsigned lds_pin[24576];
+    if (iters < 0) lds_pin[threadIdx.x] = iters;
+    Consts c = *cp;
+    constexpr int C8 = 8;
+    u64 x[C8], y[C8], w[C8], wp[C8];
+    for (int u = 0; u < C8; u++) {
+        x[u] = (threadIdx.x * 1315423911ULL + u * 977ULL) & ((1ULL << 59) - 1);
+        y[u] = (x[u] * 2654435761ULL + blockIdx.x) & ((1ULL << 59) - 1);
+        w[u] = c.w + (VTW ? (u64)threadIdx.x * 7919ULL + u : 0);
+        wp[u] = c.wp + (VTW ? (u64)threadIdx.x * 104729ULL + u : 0);
+        if (VTW) asm volatile("" : "+v"(w[u]), "+v"(wp[u]));
+    }
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters * 2; it++) {
+#pragma unroll
+        for (int u = 0; u < C8; u++) {
+            u32 y0 = lo32(y[u]), y1 = hi32(y[u]), p0 = lo32(wp[u]), p1 = hi32(wp[u]);
+            u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+            u64 T = y[u] * w[u] + h * c.nq;
+            u64 U = x[u];
+            x[u] = U + T;
+            y[u] = U + c.fourq - T;
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    u64 s = 0;
+    for (int u = 0; u < C8; u++) s ^= x[u] ^ y[u];
+    if (s == 0x12345678) out[4000000] = s + lds_pin[threadIdx.x];
+    if ((threadIdx.x & 63) == 0) {
+        size_t w_ = (blockIdx.x * blockDim.x + threadIdx.x) / 64;
+        out[3 * w_] = t1 - t0;
+        out[3 * w_ + 1] = r0;
+        out[3 * w_ + 2] = r1;
+    }
 }
 
 template <int V>
@@ -345,6 +375,7 @@ int main(int argc, char** argv)
         {"3 shoup exact harvey", k_bfly<3>}, {"4 barrett literal", k_bfly<4>}, {"5 shoup approx asm", k_bfly<5>},
         {"6 modmul approx only", k_bfly<6>}, {"7 GS harvey exact", k_bfly<7>}, {"8 GS approx lazy", k_bfly<8>},
         {"9 CT all-mad fold", k_bfly<9>}, {"10 GS all-mad", k_bfly<10>}, {"11 CT fold U", k_bfly<11>},
+        {"12 v1, 8 chains, SGPR twiddles", k_bfly_tw<false>}, {"13 v1, 8 chains, VGPR twiddles", k_bfly_tw<true>},
     };
     for (auto& s : ks) {
         run(s.n, s.k, 256, 1, iters, dc);
