@@ -129,3 +129,25 @@ def test_exact_flag_returns_the_exact_transform(native, oracle, gpu):
     ctx.inverse_batch(d, 3)
     assert np.array_equal(native.to_host(d).reshape(3, n), tern)       # and the round trip is the identity
     ctx.close()
+
+
+def test_predicate_is_sound_exhaustively_on_small_moduli(native):
+    """Every odd modulus with 8..11 bits, EVERY pair of canonical operands through the reference's reduction (numpy
+    restatement of singleBarrett): whenever the predicate says "exact" there is no under-reduction.  (The converse need
+    not hold: the predicate is a sufficient condition.)"""
+    flagged_inexact = truly_inexact = 0
+    for k in range(8, 12):
+        for q in range((1 << (k - 1)) + 1, 1 << k, 2):
+            mu = (1 << (2 * k)) // q
+            x = np.arange(q, dtype=np.uint64)
+            a = np.outer(x, x).reshape(-1)
+            s = ((a >> np.uint64(k - 2)) * np.uint64(mu)) >> np.uint64(k + 2)
+            r = a - s * np.uint64(q)
+            r = np.where(r >= q, r - np.uint64(q), r)
+            bad = bool((r >= q).any())
+            assert np.array_equal(np.where(r >= q, r - np.uint64(q), r), a % np.uint64(q))      # never off by more than one q
+            exact = native.barrett_is_exact(q)
+            assert not (exact and bad), q
+            flagged_inexact += not exact
+            truly_inexact += bad
+    assert truly_inexact > 0 and flagged_inexact >= truly_inexact
