@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU for a dry run)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time scatter -> forward+inverse -> gather from a rank-0-resident batch (SURVEY.md 8(e), report 2)")
     return ap.parse_args()
@@ -217,10 +218,13 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=args.backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
