@@ -75,7 +75,9 @@ int bfv_bootstrap(BfvParams* out, unsigned n, unsigned R, const u64* q, u64 t, u
 
 }  // namespace mi355ntt
 
-static thread_local int g_bfv_hip_error = 0;
+namespace mi355ntt {
+void record_hip_error(int e);      // capi.cpp: what mi355ntt_last_hip_error() reports
+}
 
 struct mi355ntt_bfv {
     mi355ntt_ctx* ntt = nullptr;
@@ -89,7 +91,7 @@ struct mi355ntt_bfv {
     do {                                      \
         hipError_t e__ = (expr);              \
         if (e__ != hipSuccess) {              \
-            g_bfv_hip_error = (int)e__;       \
+            record_hip_error((int)e__);       \
             return MI355NTT_EHIP;             \
         }                                     \
     } while (0)
@@ -119,7 +121,7 @@ int mi355ntt_bfv_create(mi355ntt_bfv** out, unsigned n, unsigned num_primes, con
         (e = hipMalloc(&b->d_bcm, sizeof(u64) * 2 * b->p.r)) != hipSuccess ||
         (e = hipMemcpy(b->d_prime, b->p.prime, sizeof(BfvPrime) * num_primes, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(b->d_bcm, b->p.base_change, sizeof(u64) * 2 * b->p.r, hipMemcpyHostToDevice)) != hipSuccess) {
-        g_bfv_hip_error = (int)e;
+        record_hip_error((int)e);
         mi355ntt_bfv_destroy(b);
         return e == hipErrorOutOfMemory ? MI355NTT_ENOMEM : MI355NTT_EHIP;
     }

@@ -14,6 +14,11 @@ using namespace mi355ntt;
 
 static thread_local int g_last_hip_error = 0;
 
+// shared with bfv_host.cpp so that mi355ntt_last_hip_error() covers every entry point (internal, not part of the ABI)
+namespace mi355ntt {
+void record_hip_error(int e) { g_last_hip_error = e; }
+}
+
 #define HIP_TRY(expr)                         \
     do {                                      \
         hipError_t e__ = (expr);              \
