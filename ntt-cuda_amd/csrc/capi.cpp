@@ -40,6 +40,10 @@ struct mi355ntt_ctx {
     FastTables fast;             // tables of the throughput kernels (kernels_fast.hip)
     bool literal = false;        // some prime is not barrett_exact and the caller did not ask for exact results:
                                  // transforms run the stage-per-launch kernels with the reference's arithmetic
+    // n = 2^16 (beyond the reference's dispatch): stage 1 splits the transform into two independent half-size ones whose
+    // stage `L` reads table entries [2L + h L, 2L + (h + 1) L) -- an ordinary 2^15 transform on a derived table.  `fast`
+    // then holds 2 P "virtual primes" (2 i + h) for n/2, polynomial y's half h is virtual polynomial 2 y + h.
+    bool split16 = false;
 };
 
 static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
@@ -57,12 +61,22 @@ static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
 static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
     if (c->literal) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+    if (c->split16) {
+        hipError_t e = compat_ct_stage(d_a, c->n, c->d_psi + (size_t)base * c->n, 1, num, division, mods_from(c, base, division), s);
+        if (e != hipSuccess) return e;
+        return fast_forward_batch(c->fast, d_a, 2 * num, 2 * division, 2 * base, s);
+    }
     return fast_forward_batch(c->fast, d_a, num, division, base, s);
 }
 
 static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
     if (c->literal) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+    if (c->split16) {
+        hipError_t e = fast_inverse_batch(c->fast, d_a, 2 * num, 2 * division, 2 * base, s);
+        if (e != hipSuccess) return e;
+        return compat_gs_stage(d_a, c->n, c->d_psiinv + (size_t)base * c->n, 1, num, division, mods_from(c, base, division), s);
+    }
     return fast_inverse_batch(c->fast, d_a, num, division, base, s);
 }
 
@@ -194,7 +208,29 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
         g_last_hip_error = (int)e;
         return fail(e == hipErrorOutOfMemory ? MI355NTT_ENOMEM : MI355NTT_EHIP);
     }
-    e = fast_tables_create(&c->fast, n, num_primes, c->prime, hp.data(), hi.data(), c->d_psi, c->d_psiinv);
+    if (n == 65536 && !c->literal && 2 * num_primes <= kMaxPrimes) {
+        const unsigned h_n = n / 2;
+        std::vector<u64> vp((size_t)2 * num_primes * h_n), vi((size_t)2 * num_primes * h_n);
+        PrimeParams vprime[kMaxPrimes];
+        for (unsigned i = 0; i < num_primes; i++)
+            for (unsigned h = 0; h < 2; h++) {
+                const unsigned v = 2 * i + h;
+                vprime[v] = c->prime[i];
+                vprime[v].ninv = modinv(h_n % c->prime[i].q, c->prime[i].q);       // the half-size transform scales by (n/2)^-1 ...
+                u64* tp = vp.data() + (size_t)v * h_n;                              // ... and the last GS stage halves once more
+                u64* ti = vi.data() + (size_t)v * h_n;
+                tp[0] = ti[0] = 1;
+                for (unsigned L = 1; L < h_n; L *= 2)
+                    for (unsigned p = 0; p < L; p++) {
+                        tp[L + p] = hp[(size_t)i * n + 2 * L + h * L + p];
+                        ti[L + p] = hi[(size_t)i * n + 2 * L + h * L + p];
+                    }
+            }
+        e = fast_tables_create(&c->fast, h_n, 2 * num_primes, vprime, vp.data(), vi.data(), nullptr, nullptr);
+        c->split16 = (e == hipSuccess);
+    } else {
+        e = fast_tables_create(&c->fast, n, num_primes, c->prime, hp.data(), hi.data(), c->d_psi, c->d_psiinv);
+    }
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return fail(e == hipErrorOutOfMemory ? MI355NTT_ENOMEM : MI355NTT_EHIP);
@@ -287,7 +323,8 @@ int mi355ntt_pointwise_mul(const mi355ntt_ctx* c, mi355ntt_u64* d_c, const mi355
     if (rc) return rc;
     if (!d_a || !d_b) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
-    HIP_TRY(fast_pointwise(c->fast, d_c, d_a, d_b, num, division, (hipStream_t)s));
+    if (c->split16) HIP_TRY(compat_pointwise(d_c, d_a, d_b, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s));
+    else HIP_TRY(fast_pointwise(c->fast, d_c, d_a, d_b, num, division, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
@@ -307,7 +344,7 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355
     if (rc) return rc;
     if (!d_bhat) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
-    if (c->literal) {   // the reference's own sequence (bfv_encryption.cuh:268-271) on the literal kernels
+    if (c->literal || c->split16) {   // the reference's own sequence (bfv_encryption.cuh:268-271), three calls
         HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
         HIP_TRY(compat_pointwise(d_a, d_a, d_bhat, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s));
         HIP_TRY(run_inverse(c, d_a, num, division, 0, (hipStream_t)s));

@@ -21,6 +21,11 @@ hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigne
                                 hipStream_t s);
 hipError_t compat_inverse_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
                                 hipStream_t s);
+// one stage of the above (stage `length` of the reference's loop) over the batch
+hipError_t compat_ct_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
+                           hipStream_t s);
+hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
+                           hipStream_t s);
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
                             const ModSet& m, hipStream_t s);
 hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s);

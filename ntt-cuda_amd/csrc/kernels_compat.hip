@@ -104,6 +104,20 @@ hipError_t compat_inverse_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigne
     return hipGetLastError();
 }
 
+hipError_t compat_ct_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
+                           hipStream_t s)
+{
+    ct_stage_kernel<<<dim3((n / 2 + kBlock - 1) / kBlock, num), kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    return hipGetLastError();
+}
+
+hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
+                           hipStream_t s)
+{
+    gs_stage_kernel<<<dim3((n / 2 + kBlock - 1) / kBlock, num), kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    return hipGetLastError();
+}
+
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
                             const ModSet& m, hipStream_t s)
 {

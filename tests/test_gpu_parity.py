@@ -126,6 +126,7 @@ CTX_CASES = [
     (32768, P.Q55, P.PSI55),                                                    # demo.cu:35-36
     (32768, [P.EDGE_PRIMES[b][0] for b in (62, 61, 59, 30)], [P.EDGE_PRIMES[b][1][32768] for b in (62, 61, 59, 30)]),
     (65536, [P.EDGE_PRIMES[61][0]], [P.EDGE_PRIMES[61][1][65536]]),
+    (65536, [P.EDGE_PRIMES[b][0] for b in (62, 59, 30)], [P.EDGE_PRIMES[b][1][65536] for b in (62, 59, 30)]),   # n = 2^16 runs as 2 x 2^15
     (2048, [P.REF_PARAMS[2048][0]], [P.REF_PARAMS[2048][1]]),
     (8192, [P.REF_PARAMS[8192][0]], [P.REF_PARAMS[8192][1]]),
     (16384, [P.REF_PARAMS[16384][0]], [P.REF_PARAMS[16384][1]]),
