@@ -121,7 +121,6 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 #define MI355NTT_PRIO_I3 2
 #endif
 #define MI355NTT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-// timing experiments only (tools/kbench.hip): fold the polynomial index so the batch stays in the MALL or in L2
 // Start-time stagger of the persistent workgroups: 8 phase groups, UNITS x 2048 cycles apart.  Every workgroup does the
 // same work, so without it all CUs load and store in the same instants and HBM sees bursts instead of a steady stream.
 // Measured on k_forward15 (tools/kbench.hip, warm): +7...10 % for 256...1024 polynomials with UNITS = 1 (at most
@@ -144,6 +143,7 @@ __device__ __forceinline__ void stagger_start()
         for (unsigned i = 0; i < ph * UNITS; i++) __builtin_amdgcn_s_sleep(32);
     }
 }
+// timing experiments only (tools/kbench.hip): fold the polynomial index so the batch stays in the MALL or in L2
 #ifndef MI355NTT_POLY_SLOT
 #define MI355NTT_POLY_SLOT(y) (y)
 #endif
@@ -214,6 +214,8 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     unsigned y = blockIdx.x;
     stagger_start<MI355NTT_STAGGER_INV>();
     wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, G::N * 8u), wave * 16384u, lane);
+    [[maybe_unused]] int it = 0;
+    MI355NTT_STAMP_DECL
     for (; y < num; y += gridDim.x) {
         unsigned t = t0;
         asm volatile("" : "+v"(t));      // thread-derived offsets are recomputed per polynomial, not kept live across the loop
@@ -224,20 +226,29 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
         u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
+        MI355NTT_STAMP2(it, 0);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
         gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p);
+        MI355NTT_STAMP2(it, 1);
         wave_transpose_0_to_5(v, slice, lane);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
         gs_round<LOGN, HL, 5, 0, NEAR>(v, twp, twr, t, p);
+        MI355NTT_STAMP2(it, 2);
         __syncthreads();                                  // private slices are idle from here on
+        MI355NTT_STAMP2(it, 3);
         exchange<LOGN, 5, 10>(v, lds, t);
+        MI355NTT_STAMP2(it, 4);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
         gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, twr, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+        MI355NTT_STAMP2(it, 5);
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num)
             wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, G::N * 8u), wave * 16384u, lane);
+        MI355NTT_STAMP2(it, 6);
+        it++;
     }
+    MI355NTT_STAMP_FLUSH
 }
 
 template <int HL, bool NEAR>

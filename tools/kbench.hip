@@ -66,14 +66,17 @@ int main(int argc, char** argv)
         }
         std::sort(ts.begin(), ts.end());
 #ifdef MI355NTT_STAMPS
-        if (which == 0) {
+        {
             // forward15: per-wave sums over all iterations of the time between marks:
             // slot 0: (store+issue of previous iteration ->) loop top, 1: R1 incl. load wait, 2: wait at sync, 3: exchange,
             // 4: R2, 5: T5->0 + R3 + canon, 6: row store + issue next loads
             unsigned nb = num < 256 ? num : 256;
             std::vector<unsigned long long> st((size_t)nb * 16 * 8);
             CK(hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost));
-            const char* nm[] = {"(loop top)", "R1 incl. load wait", "wait at sync", "exchange 10->5", "R2", "T5->0 + R3 + canon", "row store + issue next loads", "-"};
+            const char* nmf[] = {"(loop top)", "R1 incl. load wait", "wait at sync", "exchange 10->5", "R2", "T5->0 + R3 + canon", "row store + issue next loads", "-"};
+            // inverse15: 0 loop top, 1 R1' (bit 0 round), 2 T0->5 + R2', 3 wait at sync, 4 exchange 5->10, 5 R3' + canon, 6 store + next row loads (waited for)
+            const char* nmi[] = {"(loop top)", "R1'", "T0->5 + R2'", "wait at sync", "exchange 5->10", "R3' + canon", "store + next row loads (incl. wait)", "-"};
+            const char** nm = which == 0 ? nmf : nmi;
             double iters = (double)num / nb, tot = 0;
             for (int ph = 0; ph < 7; ph++) {
                 double acc = 0, mn = 1e18, mx = 0;
@@ -83,7 +86,8 @@ int main(int argc, char** argv)
             }
             printf("    total                          %9.0f cycles per polynomial per wave\n", tot);
             { double c = 0; for (size_t w = 0; w < (size_t)nb * 16; w++) c += (double)st[w * 8 + 7] / 16777216.0; printf("    in-kernel clock (memtime/memrealtime x 100 MHz): %.3f GHz\n", c / (nb * 16.0) * 0.1); }
-            printf("    WG0 per wave (cycles/poly): R1+wait | sync | xchg | R2 | R3 | store\n");
+            printf(which == 0 ? "    WG0 per wave (cycles/poly): R1+wait | sync | xchg | R2 | R3 | store\n"
+                              : "    WG0 per wave (cycles/poly): R1' | T+R2' | sync | xchg | R3' | store+load\n");
             for (int w = 0; w < 16; w++) {
                 printf("     w%02d", w);
                 for (int ph = 1; ph < 7; ph++) printf(" %8.0f", (double)st[w * 8 + ph] / iters);
