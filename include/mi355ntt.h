@@ -93,6 +93,10 @@ int mi355ntt_ctx_destroy(mi355ntt_ctx* ctx);
 int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_n(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_num_primes(const mi355ntt_ctx* ctx);
+/* the device the context lives on.  Every launching call on a context (or on a BFV object) runs on THAT device: the
+ * library switches to it for the duration of the call when the caller's current device differs and restores the
+ * caller's device afterwards; `stream` must be a stream of the context's device (NULL = its default stream). */
+int mi355ntt_ctx_device(const mi355ntt_ctx* ctx);
 /* per-prime derived parameters; any out pointer may be NULL */
 int mi355ntt_ctx_prime(const mi355ntt_ctx* ctx, unsigned prime_idx, mi355ntt_u64* q, mi355ntt_u64* mu,
                        unsigned* bit_length, mi355ntt_u64* psi, mi355ntt_u64* psiinv);

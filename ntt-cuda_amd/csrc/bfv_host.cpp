@@ -11,6 +11,7 @@
 #include <new>
 
 #include "bfv.hpp"
+#include "device_scope.hpp"
 
 using namespace mi355ntt;
 
@@ -95,6 +96,9 @@ struct mi355ntt_bfv {
             return MI355NTT_EHIP;             \
         }                                     \
     } while (0)
+#define BFV_ON_DEVICE(b)                                   \
+    DeviceScope scope__(mi355ntt_ctx_device((b)->ntt));    \
+    BFV_HIP(scope__.err)
 #define BFV_RC(expr)            \
     do {                        \
         int rc__ = (expr);      \
@@ -116,8 +120,10 @@ int mi355ntt_bfv_create(mi355ntt_bfv** out, unsigned n, unsigned num_primes, con
         mi355ntt_bfv_destroy(b);
         return rc;
     }
-    hipError_t e;
-    if ((e = hipMalloc(&b->d_prime, sizeof(BfvPrime) * num_primes)) != hipSuccess ||
+    DeviceScope scope(device);
+    hipError_t e = scope.err;
+    if (e != hipSuccess ||
+        (e = hipMalloc(&b->d_prime, sizeof(BfvPrime) * num_primes)) != hipSuccess ||
         (e = hipMalloc(&b->d_bcm, sizeof(u64) * 2 * b->p.r)) != hipSuccess ||
         (e = hipMemcpy(b->d_prime, b->p.prime, sizeof(BfvPrime) * num_primes, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(b->d_bcm, b->p.base_change, sizeof(u64) * 2 * b->p.r, hipMemcpyHostToDevice)) != hipSuccess) {
@@ -134,6 +140,7 @@ int mi355ntt_bfv_create(mi355ntt_bfv** out, unsigned n, unsigned num_primes, con
 int mi355ntt_bfv_destroy(mi355ntt_bfv* b)
 {
     if (!b) return MI355NTT_OK;
+    DeviceScope scope(b->ntt ? mi355ntt_ctx_device(b->ntt) : 0);
     if (b->d_prime) (void)hipFree(b->d_prime);
     if (b->d_bcm) (void)hipFree(b->d_bcm);
     if (b->ntt) mi355ntt_ctx_destroy(b->ntt);
@@ -173,6 +180,7 @@ int mi355ntt_bfv_keygen(const mi355ntt_bfv* b, mi355ntt_u64* d_secret_key, mi355
     if (!b || !d_secret_key || !d_public_key || !d_e) return MI355NTT_EINVAL;
     const unsigned R = b->p.R;
     const size_t half = (size_t)R * b->p.n;
+    BFV_ON_DEVICE(b);
     BFV_RC(mi355ntt_forward_batch(b->ntt, d_secret_key, R, R, stream));                                    /* :129 */
     BFV_RC(mi355ntt_pointwise_mul(b->ntt, d_public_key, d_public_key + half, d_secret_key, R, R, stream)); /* :131-132 */
     BFV_RC(mi355ntt_inverse_batch(b->ntt, d_public_key, R, R, stream));                                    /* :133 */
@@ -186,6 +194,7 @@ int mi355ntt_bfv_encrypt(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355nt
 {
     if (!b || !d_c || !d_public_key || !d_e || !d_m) return MI355NTT_EINVAL;
     const unsigned R = b->p.R;
+    BFV_ON_DEVICE(b);
     BFV_RC(mi355ntt_polymul_batch(b->ntt, d_c, d_public_key, 2 * R, R, stream));                           /* :268-271 */
     BFV_HIP(bfv_encrypt_tail(b->p, b->d, d_c, d_e, d_m, (hipStream_t)stream));                             /* :278-289 */
     return MI355NTT_OK;
@@ -196,6 +205,7 @@ int mi355ntt_bfv_decrypt(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355nt
 {
     if (!b || !d_c || !d_secret_key) return MI355NTT_EINVAL;
     const unsigned R = b->p.R, r = b->p.r;
+    BFV_ON_DEVICE(b);
     BFV_RC(mi355ntt_polymul_batch(b->ntt, d_c + (size_t)R * b->p.n, d_secret_key, r, R, stream));          /* :98-101 */
     BFV_HIP(bfv_decrypt_scale(b->p, b->d, d_c, (hipStream_t)stream));                                      /* :103-121 */
     BFV_HIP(bfv_decrypt_round(b->p, b->d, d_c, (hipStream_t)stream));                                      /* :126-137 */
@@ -234,6 +244,7 @@ int mi355ntt_bfv_sample_keygen(const mi355ntt_bfv* b, const void* d_in, mi355ntt
                                mi355ntt_u64* d_temp, mi355ntt_stream stream)
 {
     if (!b || !d_in || !d_secret_key || !d_public_key || !d_temp) return MI355NTT_EINVAL;
+    BFV_ON_DEVICE(b);
     BFV_HIP(bfv_sample_keygen(b->p, b->d, static_cast<const unsigned char*>(d_in), d_secret_key, d_public_key, d_temp, (hipStream_t)stream));
     return MI355NTT_OK;
 }
@@ -241,6 +252,7 @@ int mi355ntt_bfv_sample_keygen(const mi355ntt_bfv* b, const void* d_in, mi355ntt
 int mi355ntt_bfv_sample_encrypt(const mi355ntt_bfv* b, const void* d_in, mi355ntt_u64* d_c, mi355ntt_u64* d_e, mi355ntt_stream stream)
 {
     if (!b || !d_in || !d_c || !d_e) return MI355NTT_EINVAL;
+    BFV_ON_DEVICE(b);
     BFV_HIP(bfv_sample_encrypt(b->p, b->d, static_cast<const unsigned char*>(d_in), d_c, d_e, (hipStream_t)stream));
     return MI355NTT_OK;
 }
@@ -251,6 +263,7 @@ int mi355ntt_bfv_keygen_rns(const mi355ntt_bfv* b, void* d_in, mi355ntt_u64* d_s
                             mi355ntt_u64* d_temp, mi355ntt_u64 nonce, mi355ntt_stream stream)
 {
     if (!b) return MI355NTT_EINVAL;
+    BFV_ON_DEVICE(b);
     BFV_RC(mi355ntt_salsa20_keystream(d_in, mi355ntt_bfv_keygen_random_bytes(b), kDefaultKey, nonce, stream));   /* :99  */
     BFV_RC(mi355ntt_bfv_sample_keygen(b, d_in, d_secret_key, d_public_key, d_temp, stream));                      /* :112-114 */
     return mi355ntt_bfv_keygen(b, d_secret_key, d_public_key, d_temp, stream);                                    /* :129-145 */
@@ -260,6 +273,7 @@ int mi355ntt_bfv_encryption_rns(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const 
                                 mi355ntt_u64* d_e, const mi355ntt_u64* d_m, mi355ntt_u64 nonce, mi355ntt_stream stream)
 {
     if (!b) return MI355NTT_EINVAL;
+    BFV_ON_DEVICE(b);
     BFV_RC(mi355ntt_salsa20_keystream(d_in, mi355ntt_bfv_encrypt_random_bytes(b), kDefaultKey, nonce, stream));   /* :228 */
     BFV_RC(mi355ntt_bfv_sample_encrypt(b, d_in, d_c, d_e, stream));                                               /* :246 */
     return mi355ntt_bfv_encrypt(b, d_c, d_public_key, d_e, d_m, stream);                                          /* :268-289 */

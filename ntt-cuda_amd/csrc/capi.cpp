@@ -7,6 +7,7 @@
 #include <new>
 #include <vector>
 
+#include "device_scope.hpp"
 #include "hostparams.hpp"
 #include "kernels.hpp"
 
@@ -27,6 +28,10 @@ void record_hip_error(int e) { g_last_hip_error = e; }
             return MI355NTT_EHIP;             \
         }                                     \
     } while (0)
+
+#define ON_CTX_DEVICE(c)                 \
+    DeviceScope scope__((c)->device);    \
+    HIP_TRY(scope__.err)
 
 struct mi355ntt_ctx {
     unsigned n = 0;
@@ -192,7 +197,8 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
         mi355ntt_ctx_destroy(c);
         return code;
     };
-    hipError_t e = hipSetDevice(device);
+    DeviceScope scope(device);           // the caller's current device is restored on every return path
+    hipError_t e = scope.err;
     if (e != hipSuccess) { g_last_hip_error = (int)e; return fail(MI355NTT_EHIP); }
 
     size_t words = (size_t)num_primes * n;
@@ -242,6 +248,7 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
 int mi355ntt_ctx_destroy(mi355ntt_ctx* c)
 {
     if (!c) return MI355NTT_OK;
+    DeviceScope scope(c->device);
     if (c->d_psi) (void)hipFree(c->d_psi);
     if (c->d_psiinv) (void)hipFree(c->d_psiinv);
     fast_tables_destroy(&c->fast);
@@ -251,6 +258,7 @@ int mi355ntt_ctx_destroy(mi355ntt_ctx* c)
 
 unsigned mi355ntt_ctx_n(const mi355ntt_ctx* c) { return c ? c->n : 0; }
 unsigned mi355ntt_ctx_num_primes(const mi355ntt_ctx* c) { return c ? c->num_primes : 0; }
+int mi355ntt_ctx_device(const mi355ntt_ctx* c) { return c ? c->device : -1; }
 
 int mi355ntt_ctx_prime(const mi355ntt_ctx* c, unsigned i, mi355ntt_u64* q, mi355ntt_u64* mu, unsigned* bits,
                        mi355ntt_u64* psi, mi355ntt_u64* psiinv)
@@ -281,6 +289,7 @@ int mi355ntt_forward_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned nu
     int rc = check_batch(c, d_a, num, division);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
+    ON_CTX_DEVICE(c);
     HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
     return MI355NTT_OK;
 }
@@ -290,6 +299,7 @@ int mi355ntt_inverse_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned nu
     int rc = check_batch(c, d_a, num, division);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
+    ON_CTX_DEVICE(c);
     HIP_TRY(run_inverse(c, d_a, num, division, 0, (hipStream_t)s));
     return MI355NTT_OK;
 }
@@ -297,6 +307,7 @@ int mi355ntt_inverse_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned nu
 int mi355ntt_forward(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream s)
 {
     if (!c || !d_a || prime_idx >= c->num_primes) return MI355NTT_EINVAL;
+    ON_CTX_DEVICE(c);
     HIP_TRY(run_forward(c, d_a, 1, 1, prime_idx, (hipStream_t)s));
     return MI355NTT_OK;
 }
@@ -304,6 +315,7 @@ int mi355ntt_forward(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned prime_id
 int mi355ntt_inverse(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream s)
 {
     if (!c || !d_a || prime_idx >= c->num_primes) return MI355NTT_EINVAL;
+    ON_CTX_DEVICE(c);
     HIP_TRY(run_inverse(c, d_a, 1, 1, prime_idx, (hipStream_t)s));
     return MI355NTT_OK;
 }
@@ -323,6 +335,7 @@ int mi355ntt_pointwise_mul(const mi355ntt_ctx* c, mi355ntt_u64* d_c, const mi355
     if (rc) return rc;
     if (!d_a || !d_b) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
+    ON_CTX_DEVICE(c);
     if (c->split16) HIP_TRY(compat_pointwise(d_c, d_a, d_b, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s));
     else HIP_TRY(fast_pointwise(c->fast, d_c, d_a, d_b, num, division, (hipStream_t)s));
     return MI355NTT_OK;
@@ -333,6 +346,7 @@ int mi355ntt_pointwise_mul_scalar(const mi355ntt_ctx* c, mi355ntt_u64* d_a, mi35
 {
     if (!c || !d_a || prime_idx >= c->num_primes) return MI355NTT_EINVAL;
     const PrimeParams& p = c->prime[prime_idx];
+    ON_CTX_DEVICE(c);
     HIP_TRY(compat_pointwise_scalar(d_a, b, c->n, p.q, p.mu, p.k, (hipStream_t)s));
     return MI355NTT_OK;
 }
@@ -344,6 +358,7 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355
     if (rc) return rc;
     if (!d_bhat) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
+    ON_CTX_DEVICE(c);
     if (c->literal || c->split16) {   // the reference's own sequence (bfv_encryption.cuh:268-271), three calls
         HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
         HIP_TRY(compat_pointwise(d_a, d_a, d_bhat, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s));

@@ -113,14 +113,45 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 #ifndef MI355NTT_PRIO_R1
 #define MI355NTT_PRIO_R1 0      // forward: R1 feeds the exchange
 #define MI355NTT_PRIO_R2 3      //          R2 follows it
-#define MI355NTT_PRIO_R3 2
+#define MI355NTT_PRIO_R3 2      //          R3: 2 for its first three stages, then 1 (MI355NTT_PSPLIT_R3 below): 6 processes
+#define MI355NTT_PSPLIT_R3 12   //          x 300 launches each, 0.1627-0.1646 ms per 1024 transforms against 0.165-0.176
+#define MI355NTT_PRIO_R3B 1     //          (profiles/r02_priority_and_noise.txt)
 #endif
 #ifndef MI355NTT_PRIO_I1
 #define MI355NTT_PRIO_I1 3      // inverse: R2' feeds the exchange (lowest); measured +3-4 % on k_inverse15
 #define MI355NTT_PRIO_I2 0
 #define MI355NTT_PRIO_I3 2
 #endif
+#if MI355NTT_DYNPRIO
+#define MI355NTT_SETPRIO(x)
+#else
 #define MI355NTT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+// optional second priority inside a round: from scheduling group PSPLIT on (-1 = none) the wave runs at priority ..B
+#ifndef MI355NTT_PSPLIT_R1
+#define MI355NTT_PSPLIT_R1 -1
+#define MI355NTT_PRIO_R1B 0
+#endif
+#ifndef MI355NTT_PSPLIT_R2
+#define MI355NTT_PSPLIT_R2 -1
+#define MI355NTT_PRIO_R2B 0
+#endif
+#ifndef MI355NTT_PSPLIT_R3
+#define MI355NTT_PSPLIT_R3 -1
+#define MI355NTT_PRIO_R3B 0
+#endif
+#ifndef MI355NTT_PSPLIT_I1
+#define MI355NTT_PSPLIT_I1 -1
+#define MI355NTT_PRIO_I1B 0
+#endif
+#ifndef MI355NTT_PSPLIT_I2
+#define MI355NTT_PSPLIT_I2 -1
+#define MI355NTT_PRIO_I2B 0
+#endif
+#ifndef MI355NTT_PSPLIT_I3
+#define MI355NTT_PSPLIT_I3 -1
+#define MI355NTT_PRIO_I3B 0
+#endif
 // Start-time stagger of the persistent workgroups: 8 phase groups, UNITS x 2048 cycles apart.  Every workgroup does the
 // same work, so without it all CUs load and store in the same instants and HBM sees bursts instead of a steady stream.
 // Measured on k_forward15 (tools/kbench.hip, warm): +7...10 % for 256...1024 polynomials with UNITS = 1 (at most
@@ -165,7 +196,9 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
+    MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_FWD>();
+    MI355NTT_WGSTAMP(1);
     load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, t);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
@@ -177,26 +210,28 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
         MI355NTT_STAMP2(it, 0);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
-        ct_round<LOGN, HL, 10, 4, NEAR>(v, twp, twr, t, p);
+        ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 1);
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
         MI355NTT_STAMP2(it, 2);
         exchange<LOGN, 10, 5>(v, lds, t);
         MI355NTT_STAMP2(it, 3);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
-        ct_round<LOGN, HL, 5, 4, NEAR>(v, twp, twr, t, p);
+        ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 4);
         wave_transpose_5_to_0(v, slice, lane);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
-        ct_round<LOGN, HL, 0, 4, NEAR>(v, twp, twr, t, p);
+        ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMP2(it, 5);
         wave_store_rows(v, slice, make_rsrc(poly, G::N * 8u), wave * 16384u, lane);
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, t);
         MI355NTT_STAMP2(it, 6);
+        if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
     }
     MI355NTT_STAMP_FLUSH
+    MI355NTT_WGSTAMP(7);
 }
 
 template <int HL, bool NEAR>
@@ -212,7 +247,9 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
+    MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_INV>();
+    MI355NTT_WGSTAMP(1);
     wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, G::N * 8u), wave * 16384u, lane);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
@@ -228,27 +265,29 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
         MI355NTT_STAMP2(it, 0);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
-        gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 1);
         wave_transpose_0_to_5(v, slice, lane);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-        gs_round<LOGN, HL, 5, 0, NEAR>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 5, 0, NEAR, MI355NTT_PSPLIT_I2, MI355NTT_PRIO_I2B>(v, twp, twr, t, p);
         MI355NTT_STAMP2(it, 2);
         __syncthreads();                                  // private slices are idle from here on
         MI355NTT_STAMP2(it, 3);
         exchange<LOGN, 5, 10>(v, lds, t);
         MI355NTT_STAMP2(it, 4);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, twr, t, p);
-        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+        gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, t, p);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP2(it, 5);
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num)
             wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, G::N * 8u), wave * 16384u, lane);
         MI355NTT_STAMP2(it, 6);
+        if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
     }
     MI355NTT_STAMP_FLUSH
+    MI355NTT_WGSTAMP(7);
 }
 
 template <int HL, bool NEAR>
@@ -306,7 +345,7 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         exchange<LOGN, 5, 10>(v, lds, t);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
         gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, t, p);
-        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
     }
@@ -403,7 +442,7 @@ k_inv15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev*
     u64 v[32];
     load_coalesced<LOGN>(v, poly, t);
     gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p);
-    static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
     store_coalesced<LOGN>(v, poly, t);
 }
 
@@ -522,6 +561,12 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
                       hipStream_t s)
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
+#ifdef MI355NTT_ONLY_HL4N      // tools/kbench.hip: one instantiation only (compile time)
+    if constexpr (LOGN == 15) {
+        k_forward15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        return hipGetLastError();
+    }
+#else
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
@@ -558,6 +603,7 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
         else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     }
+#endif
     return hipGetLastError();
 }
 
@@ -566,6 +612,12 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
                       hipStream_t s)
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
+#ifdef MI355NTT_ONLY_HL4N
+    if constexpr (LOGN == 15) {
+        k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        return hipGetLastError();
+    }
+#else
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
@@ -597,6 +649,7 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
         else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     }
+#endif
     return hipGetLastError();
 }
 

@@ -58,8 +58,13 @@ __device__ __forceinline__ unsigned long long stamp_real()
 #define MI355NTT_STAMP2(it, slot) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = stamp_now(); sacc.sum[slot] += n_ - sacc.prev; sacc.prev = n_; __builtin_amdgcn_sched_barrier(0); }
 #define MI355NTT_STAMP_FLUSH { unsigned long long real1_ = stamp_real(), clk1_ = stamp_now(); sacc.sum[7] = ((clk1_ - clk0_) << 24) / (real1_ - real0_ + 1); /* shader cycles per 100 MHz tick, x 2^24 */ \
     if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 8; k_++) g_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k_] = sacc.sum[k_]; } }
+// workgroup timeline in s_memrealtime ticks (100 MHz): slot 0 kernel entry, 1 after the start stagger, 2 + i end of
+// iteration i (i < 5), 7 exit; written by thread 0 only
+__device__ unsigned long long* g_wg_buf;
+#define MI355NTT_WGSTAMP(slot) { if (threadIdx.x == 0) g_wg_buf[(size_t)blockIdx.x * 8 + (slot)] = stamp_real(); }
 #define MI355NTT_STAMP(slot)
 #else
+#define MI355NTT_WGSTAMP(slot)
 #define MI355NTT_STAMP(slot)
 #define MI355NTT_STAMP2(it, slot)
 #define MI355NTT_STAMP_DECL
@@ -160,6 +165,48 @@ __device__ __forceinline__ u64 mul_shoup4(u64 y, u64 w, u64 wp, u64 nq)
     u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
     return y * w + h * nq;
 }
+
+// The same product with the four cross terms y0*w1 + y1*w0 + h0*n1 + h1*n0 (only their low 32 bits matter) accumulated
+// by a chain of v_mad_u64_u32 instead of four v_mul_lo_u32 + two v_add3_u32.  Measured on gfx950 with every wave busy
+// until a common deadline (tools/ubench_issue.hip, profiles/r02_ubench_issue_costs.txt): v_mad_u64_u32 issues in 4.1
+// cycles per wave-instruction, the same as v_mul_lo_u32 / v_mul_hi_u32 / v_add3_u32 / v_lshl_add_u64 (4.0 ... 4.3; only
+// plain 32-bit add / sub / and / xor / lshr / mov are full rate, 2.2), so the chain costs 4 x 4.1 + one full-rate add
+// = 18.6 cycles against 24.3.  Inline asm, because the compiler -- knowing that only 32 bits of the chain are used --
+// rewrites it into the multiply/add3 form.  `base` rides in the 64-bit addend of the lo*lo multiply-adds (0, or the
+// butterfly's other input: the sum U + T then costs nothing).  TWS: the twiddle is wave-uniform (SGPR operands; a VOP3
+// instruction of gfx9 may read one scalar register, which every mad below respects).
+template <bool BS>
+__device__ __forceinline__ u64 mad32_chain(u32 a, u32 b, u64 c)        // a: VGPR, b: VGPR or (BS) SGPR, c: VGPR pair
+{
+    u64 d, carry;
+    if constexpr (BS) asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
+    else asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <bool BS>
+__device__ __forceinline__ u64 mad32_chain0(u32 a, u32 b)
+{
+    u64 d, carry;
+    if constexpr (BS) asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    else asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+}
+// y*w + h*(2^64 - q) + base  (mod 2^64); without base: congruent to y*w and in [0, 4q).  nq is always scalar (PrimeDev).
+template <bool TWS>
+__device__ __forceinline__ u64 mul_shoup4m_acc(u64 y, u64 w, u64 wp, u64 nq, u64 base)
+{
+    const u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
+    const u32 w0 = lo32(w), w1 = hi32(w), n0 = lo32(nq), n1 = hi32(nq);
+    const u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    const u32 h0 = lo32(h), h1 = hi32(h);
+    const u64 acc = mad32(h0, n0, mad32(y0, w0, base));
+    const u64 c = mad32_chain<true>(h1, n0, mad32_chain<true>(h0, n1, mad32_chain<TWS>(y1, w0, mad32_chain0<TWS>(y0, w1))));
+    u32 xh = hi32(acc);
+    asm("v_add_u32 %0, %0, %1" : "+v"(xh) : "v"(lo32(c)));     // (as C++ the compiler re-associates it into a 64-bit add of {0, c})
+    return ((u64)xh << 32) | lo32(acc);
+}
+template <bool TWS>
+__device__ __forceinline__ u64 mul_shoup4m(u64 y, u64 w, u64 wp, u64 nq) { return mul_shoup4m_acc<TWS>(y, w, wp, nq, 0); }
 
 // exact-quotient variant, result in [0, 2q)  (needed only when 4q does not fit: q >= 2^61... see policy)
 __device__ __forceinline__ u64 mul_shoup2(u64 y, u64 w, u64 wp, u64 nq)
@@ -503,8 +550,44 @@ __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, 
     wave_lds_fence();
 }
 
+// Both column halves' global loads issued back to back (16 x 16 B per lane in flight), then the two trips through the
+// slice: one exposed memory latency per polynomial instead of two.
+#ifndef MI355NTT_INV_MERGED_LOADS
+#define MI355NTT_INV_MERGED_LOADS 0
+#endif
+__device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
+{
+    asm volatile("" : "+v"(lane));
+    char* base = reinterpret_cast<char*>(slice);
+    const unsigned sw = lane & 7, rr = lane >> 3;
+    v4u32 x[16];
+    static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, k = i & 7, ch = i >> 3;
+        x[i] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, MI355NTT_STREAM_AUX_LD);
+    });
+    static_for<2>([&](auto cc) {
+        constexpr int ch = decltype(cc)::value;
+        static_for<8>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4)) = x[8 * ch + k];
+        });
+        wave_lds_fence();
+        static_for<8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + lane * 128 + ((m ^ row_swz(lane)) << 4));
+            v[16 * ch + 2 * m] = pr.x;
+            v[16 * ch + 2 * m + 1] = pr.y;
+        });
+        wave_lds_fence();
+    });
+}
+
 __device__ __forceinline__ void wave_load_rows(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
 {
+    if constexpr (MI355NTT_INV_MERGED_LOADS) {
+        wave_load_rows_merged(v, slice, src, wave_byte_off, lane);
+        return;
+    }
     u64 h[16];
     wave_load_rows_half<0>(h, slice, src, wave_byte_off, lane);
     static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
@@ -569,8 +652,67 @@ __device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* 
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// wave-priority hooks of the n = 2^15 kernels (s_setprio; priority outranks age in the SIMD's issue arbitration)
+// ------------------------------------------------------------------------------------------------
+// Static form: a round may lower the wave's priority from group PSPLIT on (the phases of a polynomial get descending
+// priorities so that the waves that are behind win the issue slots and all 16 reach the workgroup exchange together).
+// Dynamic form (MI355NTT_DYNPRIO = log2 of the time slice in shader cycles, 0 = off): every group start the wave sets
+// priority ((s_memtime >> SLICE) + rank of the wave on its SIMD) & 3, i.e. the four waves of a SIMD take turns at the
+// top priority -- round-robin time slicing on top of the hardware's oldest-first arbitration.
+#ifndef MI355NTT_DYNPRIO
+#define MI355NTT_DYNPRIO 0
+#endif
+__device__ __forceinline__ void dyn_prio_tick(unsigned t)
+{
+#if MI355NTT_DYNPRIO
+    // One opaque asm block (s_setprio takes an immediate, so the four cases are a compare ladder; as C++ branches they would
+    // split the straight-line round into basic blocks and wreck its register allocation).
+    const unsigned slot = __builtin_amdgcn_readfirstlane(t >> 8);            // waves w, w+4, w+8, w+12 share a SIMD
+    unsigned long long tm;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+    const unsigned p = ((unsigned)(tm >> MI355NTT_DYNPRIO) + slot) & 3u;
+    asm volatile("s_cmp_lg_u32 %0, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_setprio 0\n\t"
+                 "s_branch 4f\n"
+                 "1:\n\t"
+                 "s_cmp_lg_u32 %0, 1\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_setprio 1\n\t"
+                 "s_branch 4f\n"
+                 "2:\n\t"
+                 "s_cmp_lg_u32 %0, 2\n\t"
+                 "s_cbranch_scc1 3f\n\t"
+                 "s_setprio 2\n\t"
+                 "s_branch 4f\n"
+                 "3:\n\t"
+                 "s_setprio 3\n"
+                 "4:"
+                 :
+                 : "s"(p)
+                 : "scc", "memory");
+#else
+    (void)t;
+#endif
+}
+template <int PSPLIT, int PAFTER, int G>
+__device__ __forceinline__ void prio_hook(unsigned t)
+{
+#if MI355NTT_DYNPRIO
+    if constexpr (PSPLIT != -2) dyn_prio_tick(t);
+#else
+    if constexpr (PSPLIT >= 0 && G == PSPLIT) __builtin_amdgcn_s_setprio(PAFTER);
+    (void)t;
+#endif
+}
+
+#ifndef MI355NTT_MAD_CHAIN
+#define MI355NTT_MAD_CHAIN 1
+#endif
 // Forward (CT) stages on register bits JHI..0 of a layout with register field at bit B.
-template <int LOGN, int HL, int B, int JHI, bool NEAR = false>
+// PSPLIT / PAFTER: see prio_hook (-2 = no hook at all: kernels other than the n = 2^15 persistent ones).
+template <int LOGN, int HL, int B, int JHI, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0>
 __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
     constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
@@ -590,6 +732,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
         constexpr int s = LOGN - 1 - (B + j);
         constexpr bool red = (RMASK >> s) & 1u;
         TwPair (&Wc)[GROUP] = W[g % DEPTH];
+        prio_hook<PSPLIT, PAFTER, g>(t);
         if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
@@ -598,7 +741,15 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
             constexpr int r1 = r0 | (1 << j);
             u64 U = v[r0];
             if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
-            if constexpr (EX || NEAR || LOGN != 15) {   // (smaller n: the extra live value costs a wave of occupancy)
+            if constexpr (!EX && MI355NTT_MAD_CHAIN) {
+                // (a, b) <- (U + T, U + cq - T): the sum comes out of the multiply-add accumulator, the difference is
+                // (2U + cq) - (U + T) (exact mod 2^64 even where 2U + cq wraps, because U + cq - T itself is below 2^64)
+                u64 D = (U << 1) + cq;
+                asm("" : "+v"(D));
+                const u64 A = mul_shoup4m_acc<!VEC>(v[r1], Wc[k].w, Wc[k].wp, p.nq, U);
+                v[r0] = A;
+                v[r1] = D - A;
+            } else if constexpr (EX || NEAR || LOGN != 15) {   // (smaller n: the extra live value costs a wave of occupancy)
                 const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
                 v[r0] = U + Tm;
                 v[r1] = U + cq - Tm;
@@ -612,7 +763,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
 }
 
 // Inverse (GS) stages on register bits JLO..4 of a layout with register field at bit B.
-template <int LOGN, int HL, int B, int JLO, bool NEAR = false>
+template <int LOGN, int HL, int B, int JLO, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0>
 __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
     constexpr InvPolicy<LOGN, HL> POL{};
@@ -633,6 +784,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
         constexpr bool red = (POL.mask >> beta) & 1u;
         const u64 cq = (u64)POL.cmul[beta] * p.q;
         TwPair (&Wc)[GROUP] = W[g % DEPTH];
+        prio_hook<PSPLIT, PAFTER, g>(t);
         if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
@@ -644,12 +796,18 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
             const u64 D = X + cq - Y;
             if constexpr (last) {
                 // length = 1: single twiddle, n^-1 folded into both outputs (the reference halves every stage)
-                v[r0] = mul_shoup<EX>(S, p.ninv, p.ninv_p, p.nq);
-                v[r1] = mul_shoup<EX>(D, p.w1n, p.w1n_p, p.nq);
+                if constexpr (!EX && MI355NTT_MAD_CHAIN) {
+                    v[r0] = mul_shoup4m<true>(S, p.ninv, p.ninv_p, p.nq);
+                    v[r1] = mul_shoup4m<true>(D, p.w1n, p.w1n_p, p.nq);
+                } else {
+                    v[r0] = mul_shoup<EX>(S, p.ninv, p.ninv_p, p.nq);
+                    v[r1] = mul_shoup<EX>(D, p.w1n, p.w1n_p, p.nq);
+                }
             } else {
                 if constexpr (red) S = reduce_2q_sel<NEAR>(S, p);
                 v[r0] = S;
-                v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
+                if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r1] = mul_shoup4m<!VEC>(D, Wc[k].w, Wc[k].wp, p.nq);
+                else v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
             }
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
@@ -711,12 +869,18 @@ __device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, uns
     inv_rounds<LOGN, HL, 0>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
 }
 
-template <int HL>
+// [0, TQ*q) -> [0, q).  Near-2^k primes: the 3-instruction fold brings [0, 4q) below 2q, so one compare/select pair
+// instead of two (a compare + 64-bit subtract + two selects cost ~21 issue cycles, the fold 8.5).
+template <int HL, bool NEAR = false>
 __device__ __forceinline__ u64 canon_after_inverse(u64 x, const PrimeDev& p)
 {
     if constexpr (!Lazy<HL>::EXACT) {
-        const u64 twoq = 2 * p.q;
-        x = x >= twoq ? x - twoq : x;
+        if constexpr (NEAR) {
+            x = reduce_2q_near(x, p);
+        } else {
+            const u64 twoq = 2 * p.q;
+            x = x >= twoq ? x - twoq : x;
+        }
     }
     return canon_2q(x, p.q);
 }

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "mi355ntt_ctx_destroy": (ctypes.c_int, [vp]),
     "mi355ntt_ctx_n": (ctypes.c_uint, [vp]),
     "mi355ntt_ctx_num_primes": (ctypes.c_uint, [vp]),
+    "mi355ntt_ctx_device": (ctypes.c_int, [vp]),
     "mi355ntt_ctx_prime": (ctypes.c_int, [vp, ctypes.c_uint, u64p, u64p, u32p, u64p, u64p]),
     "mi355ntt_ctx_psi_tables": (vp, [vp]),
     "mi355ntt_ctx_psiinv_tables": (vp, [vp]),

@@ -48,21 +48,30 @@ int main(int argc, char** argv)
     unsigned long long* dstamp;
     CK(hipMalloc(&dstamp, (size_t)256 * 16 * 8 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dstamp, sizeof(dstamp)));
+    unsigned long long* dwg;
+    CK(hipMalloc(&dwg, (size_t)256 * 8 * 8));
+    CK(hipMemset(dwg, 0, (size_t)256 * 8 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_buf), &dwg, sizeof(dwg)));
 #endif
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int which = 0; which < 2; which++) {
         for (int i = 0; i < warm; i++) {
-            if (which == 0) launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
+            if (which == 0) (void)launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else (void)launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
         }
         CK(hipDeviceSynchronize());
         std::vector<float> ts;
+        // KB_B2B = L > 1: each sample times L back-to-back launches (the queue stays full, as in bench.py), else one
+        // isolated launch per sample (which includes ~10 us of host launch latency after the start event)
+        const int b2b = getenv("KB_B2B") ? atoi(getenv("KB_B2B")) : 1;
         for (int i = 0; i < reps; i++) {
             CK(hipEventRecord(e0));
-            if (which == 0) launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
+            for (int l = 0; l < b2b; l++) {
+                if (which == 0) (void)launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else (void)launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
+            }
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / b2b);
         }
         std::sort(ts.begin(), ts.end());
 #ifdef MI355NTT_STAMPS
@@ -93,6 +102,25 @@ int main(int argc, char** argv)
                 for (int ph = 1; ph < 7; ph++) printf(" %8.0f", (double)st[w * 8 + ph] / iters);
                 printf("\n");
             }
+            // workgroup timeline of the LAST launch (s_memrealtime, 10 ns ticks), relative to the earliest entry
+            std::vector<unsigned long long> wg((size_t)nb * 8);
+            CK(hipMemcpy(wg.data(), dwg, wg.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull;
+            for (unsigned b = 0; b < nb; b++) t0 = std::min(t0, wg[b * 8]);
+            auto stat = [&](const char* name, auto f) {
+                double mn = 1e18, mx = -1e18, sum = 0; unsigned cnt = 0;
+                for (unsigned b = 0; b < nb; b++) { double v = f(b); if (v < -1e17) continue; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; cnt++; }
+                printf("    wg %-34s mean %8.2f us  min %8.2f  max %8.2f  (%u wgs)\n", name, sum / cnt * 0.01, mn * 0.01, mx * 0.01, cnt);
+            };
+            stat("entry (after first entry)", [&](unsigned b) { return (double)(wg[b * 8] - t0); });
+            stat("stagger sleep", [&](unsigned b) { return (double)(wg[b * 8 + 1] - wg[b * 8]); });
+            int nit = (int)std::min<double>(5, iters);
+            for (int i = 0; i < nit; i++) {
+                char nmb[64]; snprintf(nmb, sizeof nmb, "iteration %d duration", i);
+                stat(nmb, [&](unsigned b) { return (double)(wg[b * 8 + 2 + i] - (i ? wg[b * 8 + 1 + i] : wg[b * 8 + 1])); });
+            }
+            stat("exit (after first entry)", [&](unsigned b) { return (double)(wg[b * 8 + 7] - t0); });
+            stat("exit - last iteration end", [&](unsigned b) { return (double)(wg[b * 8 + 7] - wg[b * 8 + 1 + nit]); });
         }
 #endif
         printf("%s  num=%u  median %.4f ms  min %.4f ms  => %.3f M transforms/s  (%.1f%% of 15.26M)\n", which ? "inverse" : "forward", num,
