@@ -210,13 +210,29 @@ def bfv_round_trip(torch, ntt, n, dev, with_cpu, qs, psis, label):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children BEFORE anything touches the GPU
+    (one process per GPU over RCCL, the same command line the driver uses) and relay rank 0's JSON line."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     import ntt_cuda_amd as ntt
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d -- launch with torch.distributed.run --nproc-per-node %d "
+                         "(or without a launcher, which spawns the ranks itself)\n" % (args.gpus, world, args.gpus))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     if world > 1:
@@ -247,6 +263,12 @@ def main():
     step()
     torch.cuda.synchronize()
     assert torch.equal(a, a0), "round trip broke the data"
+    # cold figure first (reported as an extra): 20 steps straight after the first launch, clocks not yet settled
+    t_c = time.perf_counter()
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    cold_pairs_per_s = batch * 20 / (time.perf_counter() - t_c)
     # The chip needs tens of milliseconds of load to settle its clocks (measured: 2.52 M pairs/s over a cold 20-step
     # region vs 2.80 M over 200 steps).  A fixed untimed pre-warm keeps short --steps runs from timing the ramp; the
     # W warm-up steps then flow straight into the timed region (no idle gap).
@@ -294,13 +316,29 @@ def main():
     dom_name, dom_ms = ("k_forward15", fwd_ms) if fwd_ms >= inv_ms else ("k_inverse15", inv_ms)
     alg_bytes = batch * BYTES_PER_TRANSFORM                       # per launch of either kernel
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9                  # GB/s
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if os.path.exists(tpath):
+    traffic, traffic_source = None, None
+    for tname in ("traffic_r02.json", "traffic_r01.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload, " \
+                                 "FETCH_SIZE x 2 per the gfx950 calibration; not collected inside this run)" % tname
+            except Exception:
+                traffic = None
+            if traffic is not None:
+                break
+    # secondary (VALU) ceiling: issue cycles of the kernel's own instruction stream at the measured steady-state cost of
+    # each instruction (tools/isa_cost.py over the shipped code object, tools/ubench_issue.hip), one polynomial per CU
+    valu = {}
+    vpath = os.path.join(ROOT, "profiles", "valu_ceiling_r02.json")
+    if os.path.exists(vpath):
         try:
-            traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            valu = json.load(open(vpath))
         except Exception:
-            traffic = None
+            valu = {}
+    vk = valu.get(dom_name, {})
+    valu_ceiling = vk.get("transforms_per_s")
     out = {
         "metric": "forward+inverse NTT/s (n=2^15, 60-bit q) per GPU; % HBM roofline",
         "value": pairs_per_s,
@@ -318,12 +356,66 @@ def main():
                                "inputs resident in HBM" % batch,
                    "n": n, "primes": P, "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": "shard%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "kernel": dom_name,
+                     "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom_name,
                      "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "pair_frac_of_hbm_peak": pairs_per_s / world * 2 * BYTES_PER_TRANSFORM / HBM_PEAK},
+                     "pair_frac_of_hbm_peak": pairs_per_s / world * 2 * BYTES_PER_TRANSFORM / HBM_PEAK,
+                     "valu_ceiling_transforms_per_s": valu_ceiling,
+                     "frac_of_valu_ceiling": (batch / (dom_ms * 1e-3) / valu_ceiling) if valu_ceiling else None,
+                     "valu_ceiling_pairs_per_s": valu.get("pairs_per_s"),
+                     "pair_frac_of_valu_ceiling": (pairs_per_s / world / valu["pairs_per_s"]) if valu.get("pairs_per_s") else None,
+                     "valu_ceiling_source": valu.get("source")},
         "kernel_ms": {"k_forward15": fwd_ms, "k_inverse15": inv_ms, "step_by_events": step_ms_events},
+        "cold_20_steps_pairs_per_s": cold_pairs_per_s * world,
     }
     if rank == 0 and world == 1 and not args.no_extras:
+        # the reference-signature entry points (forwardNTT_batch / inverseNTT_batch with the caller's tables and moduli,
+        # ntt_60bit.cuh:608,652) on the same workload: checked routing (table compared on the device before every call),
+        # trusted routing (the caller's promise), and the literal kernels (a hand-made mu keeps the call off the context)
+        import numpy as np
+        tabs_f = torch.empty((P, n), dtype=torch.int64, device=dev)
+        tabs_i = torch.empty((P, n), dtype=torch.int64, device=dev)
+        for i in range(P):
+            tp, ti = ntt.fillTablePsi128(PSI60[i], Q60[i], ntt.modinv128(PSI60[i], Q60[i]), n)
+            tabs_f[i] = torch.from_numpy(tp.view(np.int64))
+            tabs_i[i] = torch.from_numpy(ti.view(np.int64))
+        mod = ntt.Moduli(Q60)
+
+        def raw_step(m):
+            ntt.forwardNTT_batch(a, n, tabs_f, batch, P, m)
+            ntt.inverseNTT_batch(a, n, tabs_i, batch, P, m)
+
+        def pairs_rate(fn, reps):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return batch * reps / (time.perf_counter() - t0_)
+
+        raw_checked = pairs_rate(lambda: raw_step(mod), args.steps)
+        assert torch.equal(a, a0)
+        ntt.raw_trust_tables(n, tabs_f, mod)
+        ntt.raw_trust_tables(n, tabs_i, mod, inverse=True)
+        raw_trusted = pairs_rate(lambda: raw_step(mod), args.steps)
+        assert torch.equal(a, a0)
+        mu_lit = mod.mu.copy()
+        mu_lit[0] -= 1
+        lit = ntt.Moduli(Q60, mu=mu_lit, bits=mod.bits)
+        scratch = a.clone()
+
+        def lit_step():
+            ntt.forwardNTT_batch(scratch, n, tabs_f, batch, P, lit)
+            ntt.inverseNTT_batch(scratch, n, tabs_i, batch, P, lit)
+
+        raw_literal = pairs_rate(lit_step, max(2, args.steps // 10))
+        del scratch
+        out["raw_api"] = {"raw_api_pairs_per_s": raw_checked, "raw_api_trusted_pairs_per_s": raw_trusted,
+                          "raw_literal_pairs_per_s": raw_literal,
+                          "what": "forwardNTT_batch + inverseNTT_batch through the reference-signature C ABI on the bench workload: "
+                                  "checked (per-call device-side table comparison), trusted (mi355ntt_raw_trust_tables), literal kernels "
+                                  "(2 passes over memory per transform: one stage launch + the 2^14-coefficient LDS kernel)"}
         # BASELINE configs[2]: batch 256, pointwise modmul fused (NTT -> (.) -> INTT in one kernel), and configs[1]: batch 1
         b256 = synth(torch, 256, n, Q60, dev, seed=7)
         bh = synth(torch, 256, n, Q60, dev, seed=8)
@@ -395,7 +487,8 @@ def main():
                                  "what": "rank-0-resident batch: chunked scatter, forward+inverse per shard, gather back to rank 0"}
         except Exception as exc:            # never let the optional leg break the contract line
             out["end_to_end"] = {"error": repr(exc)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0's host cores, after the timed region (the other ranks wait at the final barrier): also for N > 1
         out["cpu_baseline"] = cpu_baseline(n, Q60, PSI60)
     elif rank == 0:
         out["cpu_baseline"] = None
@@ -403,6 +496,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()              # rank 0 may have spent a while in the CPU leg
         dist.destroy_process_group()
 
 

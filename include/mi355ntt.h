@@ -138,10 +138,36 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, const mi3
                            unsigned num, unsigned division, mi355ntt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Raw-parameter entry points: signature-compatible with the reference (caller supplies q, mu,
- * bit_length and reference-format device tables).  These follow Algorithm 7 (singleBarrett,
- * ntt_60bit.cuh:44-61) literally with the caller's mu/bit_length.
+ * Raw-parameter entry points: signature-compatible with the reference (the caller supplies q, mu, bit_length and
+ * reference-format device tables on every call, ntt_60bit.cuh:314,350,608,652 + the __constant__ moduli of :8-10).
+ *
+ * Routing.  A caller that passes what the reference's own bootstrap computes -- mu = floor(2^(2k)/q), bit_length =
+ * bitlen(q), tables = fillTablePsi128 of a primitive 2n-th root (60bit_ntt_test.cu:47-49, demo.cu:69,188-196) -- for
+ * moduli on which the reference's single-subtraction Barrett is exact (mi355ntt_barrett_is_exact) gets, word for word,
+ * the exact transform, so those calls run the THROUGHPUT kernels: on first sight of a (device, n, moduli, mu,
+ * bit_length, table address) the library reads the root out of the table, derives a context, compares the caller's
+ * table with the derived one, and keeps the context (<= 32, least recently used evicted; first sight synchronises
+ * the device).  Any other call (hand-made mu, a table that is not root^bitrev(i), a Barrett-inexact modulus, n outside
+ * 2^11..2^16, a table that is not 16-byte aligned) follows Algorithm 7 (singleBarrett, ntt_60bit.cuh:44-61) literally with the caller's
+ * numbers: the literal kernels (the stages inside 2^14 coefficients out of LDS + one stage launch at n = 2^15 = 2 passes
+ * over memory; the reference makes 4 and 5).
+ *   The reference reads the table on every call, so a cached context must never outlive the table's contents (a
+ * freed table whose address is handed out again, a table rewritten in place).  Default, CHECKED: in front of every
+ * transform a small kernel compares the caller's table with the context's on the device (stream-ordered, no host
+ * synchronisation), the throughput kernel runs only if they are equal and the literal kernels only if they are not:
+ * always the caller's table's result, for a few microseconds per call.  mi355ntt_raw_trust_tables() is the caller's promise that a table stays
+ * as it is: calls on it skip the check (and n = 2^16, whose split path cannot be guarded, runs the throughput kernels
+ * only then).  mi355ntt_raw_cache_clear() forgets everything; MI355NTT_RAW_LITERAL=1 in the environment disables the
+ * routing.  Calls run on the CURRENT device, as the reference's do.
  * ---------------------------------------------------------------------------------------------- */
+int mi355ntt_raw_cache_clear(void);
+/* 1 when calls with these arguments run the throughput kernels, 0 for the literal ones (derives + caches on first use) */
+int mi355ntt_raw_uses_fast_kernels(unsigned n, const mi355ntt_u64* d_table, int inverse, unsigned division,
+                                   const mi355ntt_u64* q, const mi355ntt_u64* mu, const unsigned* bit_length);
+/* promise: the table at d_table keeps its contents until mi355ntt_raw_cache_clear().  1: calls with these arguments now
+ * run the throughput kernels without the per-call comparison; 0: they run the literal kernels (nothing to trust) */
+int mi355ntt_raw_trust_tables(unsigned n, const mi355ntt_u64* d_table, int inverse, unsigned division,
+                              const mi355ntt_u64* q, const mi355ntt_u64* mu, const unsigned* bit_length);
 int mi355ntt_forward_raw(mi355ntt_u64* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q, mi355ntt_u64 mu,
                          int bit_length, const mi355ntt_u64* d_psi_table);                        /* forwardNTT :314 */
 int mi355ntt_inverse_raw(mi355ntt_u64* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q, mi355ntt_u64 mu,

@@ -3,7 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -385,6 +388,195 @@ static int fill_modset(ModSet* m, unsigned division, const mi355ntt_u64* q, cons
 
 static int check_raw_n(unsigned n) { return (is_pow2(n) && n >= 2 && n <= (1u << 20)) ? MI355NTT_OK : MI355NTT_EUNSUPPORTED; }
 
+}  // extern "C" (reopened below)
+
+// The reference's launchers take (q, mu, bit_length, device table) on every call (ntt_60bit.cuh:314,350,608,652 with the
+// __constant__ moduli of :8-10).  A caller who passes what the reference's own bootstrap computes -- mu = floor(2^(2k)/q),
+// bits = bitlen(q), tables = fillTablePsi128(psi) (60bit_ntt_test.cu:47-49, demo.cu:69,188-196) -- with moduli for which the
+// reference's single-subtraction Barrett is exact gets, word for word, the exact transform: those calls run the throughput
+// kernels on a context the library derives once per (device, n, moduli, table address) and keeps.  Anything else (a
+// hand-made mu, a table that is not psi^bitrev(i), a Barrett-inexact modulus) runs the literal kernels, which follow the
+// caller's numbers step by step.  First sight of a table costs two small synchronous copies and one compare kernel;
+// the table is assumed not to be rewritten at the same address afterwards (mi355ntt_raw_cache_clear drops everything,
+// MI355NTT_RAW_LITERAL=1 in the environment disables the routing).
+namespace {
+
+struct RawEntry {
+    int device = 0;
+    unsigned n = 0, division = 0;
+    bool inverse = false;
+    const u64* tab = nullptr;
+    u64 q[kMaxPrimes], mu[kMaxPrimes];
+    unsigned bits[kMaxPrimes];
+    mi355ntt_ctx* ctx = nullptr;       // null: literal kernels
+    unsigned long long stamp = 0;
+    // checked mode (default): the table is compared with the context's in front of every transform (guard words, kernels.hpp)
+    bool trusted = false;              // the caller promised not to rewrite the table: no per-call comparison
+    unsigned epoch = 0;
+    hipEvent_t ev = nullptr;           // last use of the guard words, for calls that arrive on another stream
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+};
+
+std::mutex g_raw_mutex;
+std::vector<RawEntry> g_raw_cache;
+unsigned long long g_raw_clock = 0;
+constexpr size_t kRawCacheMax = 32;
+
+bool raw_routing_enabled()
+{
+    static const bool on = [] {
+        const char* e = std::getenv("MI355NTT_RAW_LITERAL");
+        return !(e && e[0] && e[0] != '0');
+    }();
+    return on;
+}
+
+bool raw_key_equal(const RawEntry& e, int device, unsigned n, unsigned division, bool inverse, const u64* tab, const u64* q, const u64* mu,
+                   const unsigned* bits)
+{
+    if (e.device != device || e.n != n || e.division != division || e.inverse != inverse || e.tab != tab) return false;
+    for (unsigned i = 0; i < division; i++)
+        if (e.q[i] != q[i] || e.mu[i] != mu[i] || e.bits[i] != bits[i]) return false;
+    return true;
+}
+
+// Derive a context from what the caller passed, or return null when the call has to follow the caller's numbers literally.
+mi355ntt_ctx* raw_derive(int device, unsigned n, unsigned division, bool inverse, const u64* d_tab, const u64* q, const u64* mu,
+                         const unsigned* bits)
+{
+    if (check_n(n) != MI355NTT_OK || ((uintptr_t)d_tab & 15u) != 0) return nullptr;
+    u64 root[kMaxPrimes];
+    for (unsigned i = 0; i < division; i++) {
+        if (q[i] < 3 || !(q[i] & 1) || bits[i] != bit_length(q[i]) || mu[i] != barrett_mu(q[i], bits[i])) return nullptr;
+        if (!barrett_single_subtraction_exact(q[i], bits[i], mu[i])) return nullptr;
+        // entry n/2 of a table is root^bitrev(n/2) = root^1
+        if (hipMemcpy(&root[i], d_tab + (size_t)i * n + n / 2, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        if (root[i] == 0 || root[i] >= q[i]) return nullptr;
+        if (inverse) root[i] = modinv(root[i], q[i]);
+    }
+    mi355ntt_ctx* c = nullptr;
+    if (mi355ntt_ctx_create_ex(&c, n, division, q, root, device, 0) != MI355NTT_OK || !c) return nullptr;
+    bool same = false;
+    if (!c->literal) {
+        unsigned* d_flag = nullptr;
+        unsigned h_flag = 1;
+        if (hipMalloc((void**)&d_flag, sizeof(unsigned)) == hipSuccess) {
+            if (hipMemset(d_flag, 0, sizeof(unsigned)) == hipSuccess &&
+                compat_tables_differ(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, d_flag, nullptr) == hipSuccess &&
+                hipMemcpy(&h_flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess)
+                same = (h_flag == 0);
+            (void)hipFree(d_flag);
+        }
+    }
+    if (!same) {
+        mi355ntt_ctx_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void raw_entry_release(RawEntry& e)
+{
+    if (e.ctx) mi355ntt_ctx_destroy(e.ctx);
+    if (e.ev) (void)hipEventDestroy(e.ev);
+    e.ctx = nullptr;
+    e.ev = nullptr;
+}
+
+// The cache entry of this raw call (g_raw_mutex held by the caller); entry->ctx is the context that serves it with the
+// throughput kernels, or null (literal kernels).  Null when the routing is off.
+RawEntry* raw_lookup(unsigned n, unsigned division, bool inverse, const u64* d_tab, const u64* q, const u64* mu, const unsigned* bits)
+{
+    if (!raw_routing_enabled()) return nullptr;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    for (RawEntry& e : g_raw_cache)
+        if (raw_key_equal(e, device, n, division, inverse, d_tab, q, mu, bits)) {
+            e.stamp = ++g_raw_clock;
+            return &e;
+        }
+    RawEntry e;
+    e.device = device; e.n = n; e.division = division; e.inverse = inverse; e.tab = d_tab;
+    for (unsigned i = 0; i < division; i++) { e.q[i] = q[i]; e.mu[i] = mu[i]; e.bits[i] = bits[i]; }
+    e.ctx = raw_derive(device, n, division, inverse, d_tab, q, mu, bits);
+    (void)hipGetLastError();
+    e.stamp = ++g_raw_clock;
+    if (g_raw_cache.size() >= kRawCacheMax) {          // evict the least recently used entry
+        size_t victim = 0;
+        for (size_t i = 1; i < g_raw_cache.size(); i++)
+            if (g_raw_cache[i].stamp < g_raw_cache[victim].stamp) victim = i;
+        raw_entry_release(g_raw_cache[victim]);
+        g_raw_cache[victim] = e;
+        return &g_raw_cache[victim];
+    }
+    g_raw_cache.push_back(e);
+    return &g_raw_cache.back();
+}
+
+// One transform of a raw call.  Trusted table: the throughput kernels.  Otherwise the checked sequence: compare the
+// caller's table with the context's (device side, ~2 MB of reads for 4 primes at n = 2^15), the throughput kernel guarded by
+// the result, and the literal kernels guarded the other way round -- whichever the table calls for transforms the data.
+hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d_tab, unsigned num, unsigned division, const ModSet& m,
+                   hipStream_t s)
+{
+    const mi355ntt_ctx* c = e ? e->ctx : nullptr;
+    if (!c || (c->split16 && !e->trusted))
+        return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
+    if (e->trusted) return inverse ? run_inverse(c, d_a, num, division, 0, s) : run_forward(c, d_a, num, division, 0, s);
+    hipError_t err;
+    if (!e->ev && (err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming)) != hipSuccess) return err;
+    if (e->used && e->last_stream != s && (err = hipStreamWaitEvent(s, e->ev, 0)) != hipSuccess) return err;
+    unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);
+    if (++e->epoch == 0) e->epoch = 1;
+    if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s)) != hipSuccess) return err;
+    err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
+    if (err != hipSuccess) return err;
+    err = inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s, guard) : compat_forward_batch(d_a, n, d_tab, num, division, m, s, guard);
+    if (err != hipSuccess) return err;
+    e->used = true;
+    e->last_stream = s;
+    return hipEventRecord(e->ev, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355ntt_raw_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lock(g_raw_mutex);
+    for (RawEntry& e : g_raw_cache) raw_entry_release(e);
+    g_raw_cache.clear();
+    return MI355NTT_OK;
+}
+
+/* The caller promises that the table at d_table keeps its contents (until mi355ntt_raw_cache_clear): calls with these
+ * arguments skip the per-call comparison.  1: such calls now run the throughput kernels unchecked, 0: they run the literal
+ * kernels (nothing to trust). */
+int mi355ntt_raw_trust_tables(unsigned n, const mi355ntt_u64* d_table, int inverse, unsigned division, const mi355ntt_u64* q,
+                              const mi355ntt_u64* mu, const unsigned* bits)
+{
+    ModSet m;
+    if (!d_table || check_raw_n(n) != MI355NTT_OK || fill_modset(&m, division, q, mu, bits) != MI355NTT_OK) return 0;
+    std::lock_guard<std::mutex> lock(g_raw_mutex);
+    RawEntry* e = raw_lookup(n, division, inverse != 0, d_table, q, mu, bits);
+    if (!e || !e->ctx) return 0;
+    e->trusted = true;
+    return 1;
+}
+
+/* 1: calls with these arguments run the throughput kernels, 0: the literal kernels (derives and caches on first use) */
+int mi355ntt_raw_uses_fast_kernels(unsigned n, const mi355ntt_u64* d_table, int inverse, unsigned division, const mi355ntt_u64* q,
+                                   const mi355ntt_u64* mu, const unsigned* bits)
+{
+    ModSet m;
+    if (!d_table || check_raw_n(n) != MI355NTT_OK || fill_modset(&m, division, q, mu, bits) != MI355NTT_OK) return 0;
+    std::lock_guard<std::mutex> lock(g_raw_mutex);
+    const RawEntry* e = raw_lookup(n, division, inverse != 0, d_table, q, mu, bits);
+    return (e && e->ctx && (!e->ctx->split16 || e->trusted)) ? 1 : 0;
+}
+
 int mi355ntt_forward_batch_raw(mi355ntt_u64* d_a, unsigned n, const mi355ntt_u64* d_tabs, unsigned num, unsigned division,
                                const mi355ntt_u64* q, const mi355ntt_u64* mu, const unsigned* bits, mi355ntt_stream s)
 {
@@ -395,7 +587,9 @@ int mi355ntt_forward_batch_raw(mi355ntt_u64* d_a, unsigned n, const mi355ntt_u64
     rc = fill_modset(&m, division, q, mu, bits);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
-    HIP_TRY(compat_forward_batch(d_a, n, d_tabs, num, division, m, (hipStream_t)s));
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(g_raw_mutex);       // one call's launches stay together on the stream
+    HIP_TRY(raw_run(raw_lookup(n, division, false, d_tabs, q, mu, bits), false, d_a, n, d_tabs, num, division, m, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
@@ -409,7 +603,9 @@ int mi355ntt_inverse_batch_raw(mi355ntt_u64* d_a, unsigned n, const mi355ntt_u64
     rc = fill_modset(&m, division, q, mu, bits);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
-    HIP_TRY(compat_inverse_batch(d_a, n, d_tabs, num, division, m, (hipStream_t)s));
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(g_raw_mutex);
+    HIP_TRY(raw_run(raw_lookup(n, division, true, d_tabs, q, mu, bits), true, d_a, n, d_tabs, num, division, m, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
@@ -436,6 +632,7 @@ int mi355ntt_barrett_raw(mi355ntt_u64* d_c, const mi355ntt_u64* d_a, const mi355
     int rc = fill_modset(&m, division, q, mu, bits);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
+    (void)hipGetLastError();
     HIP_TRY(compat_pointwise(d_c, d_a, d_b, n, num, division, m, (hipStream_t)s));
     return MI355NTT_OK;
 }

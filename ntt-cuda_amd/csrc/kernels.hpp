@@ -16,11 +16,17 @@ struct ModSet {
     unsigned k[kMaxPrimes];
 };
 
+// Checked raw calls (capi.cpp): the caller's table is compared with the cached context's on the device in front of every
+// transform.  Guard words g = {current epoch, epoch of the last mismatch}: the throughput kernels launched with
+// kGuardBit set in prime_base return at once when g[0] == g[1] (this call's table is not the cached one), the literal
+// kernels launched with a guard pointer return at once when g[0] != g[1] -- exactly one of the two transforms the data.
+constexpr unsigned kGuardBit = 0x80000000u;
+
 // ---- literal stage-per-launch kernels (kernels_compat.hip) ----
 hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
-                                hipStream_t s);
+                                hipStream_t s, const unsigned* guard = nullptr);
 hipError_t compat_inverse_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
-                                hipStream_t s);
+                                hipStream_t s, const unsigned* guard = nullptr);
 // one stage of the above (stage `length` of the reference's loop) over the batch
 hipError_t compat_ct_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
                            hipStream_t s);
@@ -29,6 +35,10 @@ hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned len
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
                             const ModSet& m, hipStream_t s);
 hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s);
+// *d_flag |= 1 when two sets of `count` reference-format tables differ in an entry the transforms read (index != 0)
+hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_flag, hipStream_t s);
+// the same as a stream-ordered check: guard[0] = epoch, and guard[1] = epoch when the tables differ
+hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s);
 
 // ---- throughput kernels (kernels_fast.hip) ----
 // Device tables private to the fast path.  Built once per context from the reference-format tables.
@@ -40,7 +50,9 @@ struct FastTables {
     // load fetches both.  Same indexing as the reference tables (entry length+p for stage `length`).
     u64* d_fwd = nullptr;      // psi^bitrev(i)
     u64* d_inv = nullptr;      // psi^-bitrev(i)
-    void* d_primes = nullptr;  // [P] PrimeDev records (ntt_core.cuh)
+    void* d_primes = nullptr;  // [P] PrimeDev records (ntt_core.cuh); the record BEFORE it holds the guard words {current epoch,
+                               // epoch of the last table mismatch} of the checked raw calls (kGuardBit, capi.cpp)
+    void* d_primes_alloc = nullptr;
     int hl = 6;                // bits 0-3: headroom class = min over primes of (64 - bit length), capped at 6; bit 4: all primes near 2^k
     const u64* d_psi = nullptr;     // reference-format tables owned by the context (fallback path)
     const u64* d_psiinv = nullptr;

@@ -9,6 +9,8 @@
 //
 // Reference counterparts (BFV_Scheme/): CTBasedNTTInner(_batch) ntt_60bit.cuh:192-223,527-561;
 // GSBasedINTTInner(_batch) :225-265,563-606; barrett* poly_arithmetic.cuh:9-126.
+#include <cstdint>
+
 #include "kernels.hpp"
 #include "modarith.cuh"
 
@@ -18,63 +20,113 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// One CT stage over a batch.  blockIdx.y = polynomial, modulus index = y % division
-// (ntt_60bit.cuh:391-394), data offset y*n (:404), table offset index*n (:422).
+// One CT stage over a batch.  The reference puts the polynomial in blockIdx.y (ntt_60bit.cuh:391-394); a grid's y extent
+// stops at 65535, so here the grid is one-dimensional: block b works on polynomial b / bpp (bpp = blocks per polynomial,
+// passed as a shift; n is a power of two; the grid is capped and strides over the `blocks` blocks), modulus index = y % division, data offset y*n (:404), table offset index*n (:422).
 __global__ void __launch_bounds__(kBlock) ct_stage_kernel(u64* __restrict__ a, const u64* __restrict__ tabs, unsigned n,
-                                                          unsigned length, unsigned division, ModSet m)
+                                                          unsigned length, unsigned division, unsigned bpp_shift, unsigned blocks, ModSet m,
+                                                          const unsigned* __restrict__ guard)
 {
-    unsigned y = blockIdx.y;
-    unsigned idx = y % division;
-    u64 q = m.q[idx], mu = m.mu[idx];
-    u32 k = m.k[idx];
-    unsigned g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= n / 2) return;
-    unsigned step = (n / length) / 2;
-    unsigned p = g / step;
-    unsigned j = p * step * 2 + (g % step);
-    u64* poly = a + (size_t)y * n;
-    u64 psi = tabs[(size_t)idx * n + length + p];
-    u64 U = poly[j];
-    u64 V = barrett_mul(poly[j + step], psi, q, mu, k);
-    poly[j] = add_mod(U, V, q);
-    poly[j + step] = sub_mod(U, V, q);
+    if (guard && guard[0] != guard[1]) return;        // fallback leg of a checked raw call: the throughput kernel did the work
+    for (unsigned blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
+        unsigned y = blk >> bpp_shift;
+        unsigned idx = y % division;
+        u64 q = m.q[idx], mu = m.mu[idx];
+        u32 k = m.k[idx];
+        unsigned g = (blk & ((1u << bpp_shift) - 1u)) * kBlock + threadIdx.x;
+        if (g >= n / 2) continue;
+        unsigned step = (n / length) / 2;
+        unsigned p = g / step;
+        unsigned j = p * step * 2 + (g % step);
+        u64* poly = a + (size_t)y * n;
+        u64 psi = tabs[(size_t)idx * n + length + p];
+        u64 U = poly[j];
+        u64 V = barrett_mul(poly[j + step], psi, q, mu, k);
+        poly[j] = add_mod(U, V, q);
+        poly[j + step] = sub_mod(U, V, q);
+    }
 }
 
 // One GS stage with the n^-1 halving (ntt_60bit.cuh:225-265)
 __global__ void __launch_bounds__(kBlock) gs_stage_kernel(u64* __restrict__ a, const u64* __restrict__ tabs, unsigned n,
-                                                          unsigned length, unsigned division, ModSet m)
+                                                          unsigned length, unsigned division, unsigned bpp_shift, unsigned blocks, ModSet m,
+                                                          const unsigned* __restrict__ guard)
 {
-    unsigned y = blockIdx.y;
-    unsigned idx = y % division;
-    u64 q = m.q[idx], mu = m.mu[idx];
-    u32 k = m.k[idx];
-    unsigned g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= n / 2) return;
-    unsigned step = (n / length) / 2;
-    unsigned p = g / step;
-    unsigned j = p * step * 2 + (g % step);
-    u64* poly = a + (size_t)y * n;
-    u64 psiinv = tabs[(size_t)idx * n + length + p];
-    u64 q2 = (q + 1) >> 1;
-    u64 U = poly[j];
-    u64 V = poly[j + step];
-    poly[j] = half_mod(add_mod(U, V, q), q2);
-    u64 d = barrett_mul(sub_mod(U, V, q), psiinv, q, mu, k);
-    poly[j + step] = half_mod(d, q2);
+    if (guard && guard[0] != guard[1]) return;
+    for (unsigned blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
+        unsigned y = blk >> bpp_shift;
+        unsigned idx = y % division;
+        u64 q = m.q[idx], mu = m.mu[idx];
+        u32 k = m.k[idx];
+        unsigned g = (blk & ((1u << bpp_shift) - 1u)) * kBlock + threadIdx.x;
+        if (g >= n / 2) continue;
+        unsigned step = (n / length) / 2;
+        unsigned p = g / step;
+        unsigned j = p * step * 2 + (g % step);
+        u64* poly = a + (size_t)y * n;
+        u64 psiinv = tabs[(size_t)idx * n + length + p];
+        u64 q2 = (q + 1) >> 1;
+        u64 U = poly[j];
+        u64 V = poly[j + step];
+        poly[j] = half_mod(add_mod(U, V, q), q2);
+        u64 d = barrett_mul(sub_mod(U, V, q), psiinv, q, mu, k);
+        poly[j + step] = half_mod(d, q2);
+    }
 }
 
-// c[i] = a[i] * b[i] mod q[y % division]   (barrett / barrett_batch / barrett_batch_3param)
+// c[i] = a[i] * b[i] mod q[y % division]   (barrett / barrett_batch / barrett_batch_3param).  One block row per
+// polynomial (bpp blocks, grid-stride over the polynomial); VEC: two coefficients (16 bytes) per lane and access.
+template <bool VEC>
 __global__ void __launch_bounds__(kBlock) pointwise_kernel(u64* __restrict__ c, const u64* __restrict__ a,
-                                                           const u64* __restrict__ b, unsigned n, unsigned division, ModSet m)
+                                                           const u64* __restrict__ b, unsigned n, unsigned division, unsigned bpp, ModSet m)
 {
-    unsigned y = blockIdx.y;
-    unsigned idx = y % division;
-    u64 q = m.q[idx], mu = m.mu[idx];
-    u32 k = m.k[idx];
-    unsigned x = blockIdx.x * kBlock + threadIdx.x;
-    if (x >= n) return;
-    size_t i = (size_t)y * n + x;
-    c[i] = barrett_mul(a[i], b[i], q, mu, k);
+    const unsigned y = blockIdx.x / bpp, bx = blockIdx.x % bpp;
+    const unsigned idx = y % division;
+    const u64 q = m.q[idx], mu = m.mu[idx];
+    const u32 k = m.k[idx];
+    const size_t base = (size_t)y * n;
+    if constexpr (VEC) {
+        const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a + base);
+        const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b + base);
+        ulonglong2* c2 = reinterpret_cast<ulonglong2*>(c + base);
+        for (unsigned x = bx * kBlock + threadIdx.x; x < n / 2; x += bpp * kBlock) {
+            const ulonglong2 u = a2[x], w = b2[x];
+            ulonglong2 r;
+            r.x = barrett_mul(u.x, w.x, q, mu, k);
+            r.y = barrett_mul(u.y, w.y, q, mu, k);
+            c2[x] = r;
+        }
+    } else {
+        for (unsigned x = bx * kBlock + threadIdx.x; x < n; x += bpp * kBlock) c[base + x] = barrett_mul(a[base + x], b[base + x], q, mu, k);
+    }
+}
+
+// 1 where two table sets differ in an entry the transforms read (entry 0 of every table is never read:
+// stage `length` reads [length, 2 length)): the raw entry points use it once per (table, moduli) to decide whether a
+// caller's table is the one a context derives from (q, psi).
+__global__ void __launch_bounds__(kBlock) tables_differ_kernel(const u64* __restrict__ x, const u64* __restrict__ y, unsigned n,
+                                                               unsigned count, unsigned* __restrict__ flag)
+{
+    bool diff = false;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)count * n; i += (size_t)gridDim.x * kBlock)
+        if ((i & (n - 1)) != 0 && x[i] != y[i]) diff = true;
+    if (diff) atomicOr(flag, 1u);
+}
+
+// Stream-ordered form of the same comparison (checked raw calls): guard[0] <- epoch; guard[1] <- epoch where they differ.
+__global__ void __launch_bounds__(kBlock) tables_check_kernel(const u64* __restrict__ x, const u64* __restrict__ y, unsigned n,
+                                                              unsigned count, unsigned* __restrict__ guard, unsigned epoch)
+{
+    bool diff = false;
+    const ulonglong2* x2 = reinterpret_cast<const ulonglong2*>(x);
+    const ulonglong2* y2 = reinterpret_cast<const ulonglong2*>(y);
+    const size_t pairs = (size_t)count * n / 2;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += (size_t)gridDim.x * kBlock) {
+        const ulonglong2 u = x2[i], v = y2[i];
+        if (u.y != v.y || (u.x != v.x && ((2 * i) & (n - 1)) != 0)) diff = true;      // entry 0 of a table is never read
+    }
+    if (diff) atomicMax(guard + 1, epoch);
+    if (blockIdx.x == 0 && threadIdx.x == 0) guard[0] = epoch;
 }
 
 // a[i] = a[i] * b mod q   (barrett_int)
@@ -85,112 +137,189 @@ __global__ void __launch_bounds__(kBlock) pointwise_scalar_kernel(u64* __restric
     a[x] = barrett_mul(a[x], b, q, mu, k);
 }
 
-// All stages of one polynomial in one launch, polynomial resident in LDS (n * 8 B <= 128 KiB): the same butterflies on the
-// same indices as the stage kernels above (the reference's CTBasedNTTInnerSingle / GSBasedINTTInnerSingle do the same
-// inside their block-private slices), so the same words.  One 1024-thread workgroup per polynomial.
-template <int LOGN, bool FWD>
-__global__ void __launch_bounds__(1024) literal_lds_kernel(u64* __restrict__ a, const u64* __restrict__ tabs, unsigned division, ModSet m)
+// All stages that fit a slice of 2^LOGS coefficients in one launch, the slice resident in LDS (2^LOGS * 8 B <= 128 KiB):
+// the same butterflies on the same indices as the stage kernels above (the reference's CTBasedNTTInnerSingle /
+// GSBasedINTTInnerSingle do the same inside their block-private slices, ntt_60bit.cuh:63-190), so the same words.
+// One 1024-thread workgroup per slice; a polynomial has n >> LOGS slices.  n <= 2^14: the whole transform.  Larger n: the
+// stages with length < slices-per-polynomial couple the slices and run as stage launches around this kernel -- at
+// n = 2^15 one stage launch + this kernel = 2 passes over memory (the reference: 3 + 1 forward, 1 + 4 inverse,
+// ntt_60bit.cuh:318-324,354-359).
+template <int LOGS, bool FWD>
+__global__ void __launch_bounds__(1024) literal_lds_kernel(u64* __restrict__ a, const u64* __restrict__ tabs, unsigned n, unsigned division,
+                                                           unsigned slices, ModSet m, const unsigned* __restrict__ guard)
 {
-    constexpr unsigned n = 1u << LOGN, T = n / 2 < 1024 ? n / 2 : 1024, PER = n / 2 / T;
-    __shared__ u64 sh[n];
-    const unsigned y = blockIdx.x, idx = y % division, t = threadIdx.x;
-    const u64 q = m.q[idx], mu = m.mu[idx];
-    const u32 k = m.k[idx];
-    u64* poly = a + (size_t)y * n;
-    const u64* tab = tabs + (size_t)idx * n;
-    if (t < T)
-        for (unsigned i = t; i < n; i += T) sh[i] = poly[i];
-    __syncthreads();
-    if constexpr (FWD) {
-        for (unsigned length = 1; length < n; length *= 2) {
-            const unsigned step = (n / length) / 2;
-            if (t < T)
-                for (unsigned it = 0; it < PER; it++) {
-                    const unsigned g = t + it * T, p = g / step, j = p * step * 2 + (g % step);
-                    const u64 U = sh[j];
-                    const u64 V = barrett_mul(sh[j + step], tab[length + p], q, mu, k);
-                    sh[j] = add_mod(U, V, q);
-                    sh[j + step] = sub_mod(U, V, q);
-                }
-            __syncthreads();
+    if (guard && guard[0] != guard[1]) return;
+    constexpr unsigned ns = 1u << LOGS, T = ns / 2 < 1024 ? ns / 2 : 1024, PER = ns / 2 / T;
+    __shared__ u64 sh[ns];
+    const unsigned spp = n >> LOGS;                       // slices per polynomial (a power of two)
+    const unsigned t = threadIdx.x;
+    for (unsigned sl = blockIdx.x; sl < slices; sl += gridDim.x) {       // (uniform per workgroup: the barriers below are safe)
+        const unsigned y = sl / spp, h = sl % spp, idx = y % division;
+        const u64 q = m.q[idx], mu = m.mu[idx];
+        const u32 k = m.k[idx];
+        u64* slice = a + (size_t)y * n + (size_t)h * ns;
+        const u64* tab = tabs + (size_t)idx * n;
+        const unsigned g0 = h * (ns / 2);                // first butterfly index of this slice within the polynomial
+        if (t < T)
+            for (unsigned i = t; i < ns; i += T) sh[i] = slice[i];
+        __syncthreads();
+        if constexpr (FWD) {
+            for (unsigned length = spp; length < n; length *= 2) {
+                const unsigned step = (n / length) / 2;
+                if (t < T)
+                    for (unsigned it = 0; it < PER; it++) {
+                        const unsigned g = g0 + t + it * T, p = g / step, j = p * step * 2 + (g % step) - h * ns;
+                        const u64 U = sh[j];
+                        const u64 V = barrett_mul(sh[j + step], tab[length + p], q, mu, k);
+                        sh[j] = add_mod(U, V, q);
+                        sh[j + step] = sub_mod(U, V, q);
+                    }
+                __syncthreads();
+            }
+        } else {
+            const u64 q2 = (q + 1) >> 1;
+            for (unsigned length = n / 2; length >= spp && length >= 1; length /= 2) {
+                const unsigned step = (n / length) / 2;
+                if (t < T)
+                    for (unsigned it = 0; it < PER; it++) {
+                        const unsigned g = g0 + t + it * T, p = g / step, j = p * step * 2 + (g % step) - h * ns;
+                        const u64 U = sh[j], V = sh[j + step];
+                        sh[j] = half_mod(add_mod(U, V, q), q2);
+                        sh[j + step] = half_mod(barrett_mul(sub_mod(U, V, q), tab[length + p], q, mu, k), q2);
+                    }
+                __syncthreads();
+            }
         }
-    } else {
-        const u64 q2 = (q + 1) >> 1;
-        for (unsigned length = n / 2; length >= 1; length /= 2) {
-            const unsigned step = (n / length) / 2;
-            if (t < T)
-                for (unsigned it = 0; it < PER; it++) {
-                    const unsigned g = t + it * T, p = g / step, j = p * step * 2 + (g % step);
-                    const u64 U = sh[j], V = sh[j + step];
-                    sh[j] = half_mod(add_mod(U, V, q), q2);
-                    sh[j + step] = half_mod(barrett_mul(sub_mod(U, V, q), tab[length + p], q, mu, k), q2);
-                }
-            __syncthreads();
-        }
+        if (t < T)
+            for (unsigned i = t; i < ns; i += T) slice[i] = sh[i];
+        __syncthreads();                                  // the next slice reuses the image
     }
-    if (t < T)
-        for (unsigned i = t; i < n; i += T) poly[i] = sh[i];
 }
 
+unsigned log2u(unsigned x)
+{
+    unsigned r = 0;
+    while ((1u << r) < x) r++;
+    return r;
+}
+
+// stage launches: 1-D grid of (n / 2 / kBlock) blocks per polynomial
 template <bool FWD>
-bool launch_literal_lds(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m, hipStream_t s)
+void launch_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m, hipStream_t s,
+                  const unsigned* guard = nullptr)
+{
+    const unsigned bpp = (n / 2 + kBlock - 1) / kBlock, sh = log2u(bpp);
+    const unsigned long long total = (unsigned long long)num << sh;
+    const unsigned blocks = total > 0xffffffffull ? 0xffffffffu : (unsigned)total;
+    const unsigned grid = blocks < 8192u ? blocks : 8192u;          // capped: a guarded launch that has nothing to do must cost ~nothing
+    if (FWD) ct_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, sh, blocks, m, guard);
+    else gs_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, sh, blocks, m, guard);
+}
+
+// workgroups of the LDS kernel: as many as can be resident (160 KiB of LDS per CU, 256 CUs), each strides over the slices
+unsigned lds_grid(unsigned slices, int logs)
+{
+    const unsigned per_cu = 163840u / (8u << logs) ? 163840u / (8u << logs) : 1u;
+    const unsigned cap = 256u * (per_cu > 2 ? 2 : per_cu);          // 1024-thread workgroups: at most two per CU
+    return slices < cap ? slices : cap;
+}
+
+// the stages inside LDS-sized slices; returns the number of slices per polynomial it used (0: n not served)
+template <bool FWD>
+unsigned launch_literal_lds(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m, hipStream_t s,
+                            const unsigned* guard)
 {
     switch (n) {
-    case 2048: literal_lds_kernel<11, FWD><<<num, 1024, 0, s>>>(d_a, d_tabs, division, m); return true;
-    case 4096: literal_lds_kernel<12, FWD><<<num, 1024, 0, s>>>(d_a, d_tabs, division, m); return true;
-    case 8192: literal_lds_kernel<13, FWD><<<num, 1024, 0, s>>>(d_a, d_tabs, division, m); return true;
-    case 16384: literal_lds_kernel<14, FWD><<<num, 1024, 0, s>>>(d_a, d_tabs, division, m); return true;
-    default: return false;
+    case 2048: literal_lds_kernel<11, FWD><<<lds_grid(num, 11), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    case 4096: literal_lds_kernel<12, FWD><<<lds_grid(num, 12), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    case 8192: literal_lds_kernel<13, FWD><<<lds_grid(num, 13), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    case 16384: literal_lds_kernel<14, FWD><<<lds_grid(num, 14), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    default: break;
     }
+    if (n >= 32768 && n <= (1u << 20) && (n & (n - 1)) == 0) {
+        const unsigned spp = n >> 14;
+        if ((unsigned long long)num * spp > 0x7fffffffull) return 0;
+        literal_lds_kernel<14, FWD><<<lds_grid(num * spp, 14), 1024, 0, s>>>(d_a, d_tabs, n, division, num * spp, m, guard);
+        return spp;
+    }
+    return 0;
 }
 
 }  // namespace
 
 hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
-                                hipStream_t s)
+                                hipStream_t s, const unsigned* guard)
 {
-    if (launch_literal_lds<true>(d_a, n, d_tabs, num, division, m, s)) return hipGetLastError();
-    dim3 grid((n / 2 + kBlock - 1) / kBlock, num);
-    for (unsigned length = 1; length < n; length *= 2)
-        ct_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    if (n >= 32768 && (n & (n - 1)) == 0 && n <= (1u << 20)) {
+        // stages 1 .. spp/2 couple the LDS slices: stage launches first, then everything else out of LDS
+        const unsigned spp = n >> 14;
+        for (unsigned length = 1; length < spp; length *= 2) launch_stage<true>(d_a, n, d_tabs, length, num, division, m, s, guard);
+        if (launch_literal_lds<true>(d_a, n, d_tabs, num, division, m, s, guard)) return hipGetLastError();
+        for (unsigned length = spp; length < n; length *= 2) launch_stage<true>(d_a, n, d_tabs, length, num, division, m, s, guard);
+        return hipGetLastError();
+    }
+    if (launch_literal_lds<true>(d_a, n, d_tabs, num, division, m, s, guard)) return hipGetLastError();
+    for (unsigned length = 1; length < n; length *= 2) launch_stage<true>(d_a, n, d_tabs, length, num, division, m, s, guard);
     return hipGetLastError();
 }
 
 hipError_t compat_inverse_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
-                                hipStream_t s)
+                                hipStream_t s, const unsigned* guard)
 {
-    if (launch_literal_lds<false>(d_a, n, d_tabs, num, division, m, s)) return hipGetLastError();
-    dim3 grid((n / 2 + kBlock - 1) / kBlock, num);
-    for (unsigned length = n / 2; length >= 1; length /= 2)
-        gs_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    if (n >= 32768 && (n & (n - 1)) == 0 && n <= (1u << 20)) {
+        const unsigned spp = n >> 14;
+        if (launch_literal_lds<false>(d_a, n, d_tabs, num, division, m, s, guard)) {
+            for (unsigned length = spp / 2; length >= 1; length /= 2) launch_stage<false>(d_a, n, d_tabs, length, num, division, m, s, guard);
+            return hipGetLastError();
+        }
+    } else if (launch_literal_lds<false>(d_a, n, d_tabs, num, division, m, s, guard)) {
+        return hipGetLastError();
+    }
+    for (unsigned length = n / 2; length >= 1; length /= 2) launch_stage<false>(d_a, n, d_tabs, length, num, division, m, s, guard);
     return hipGetLastError();
 }
 
 hipError_t compat_ct_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
                            hipStream_t s)
 {
-    ct_stage_kernel<<<dim3((n / 2 + kBlock - 1) / kBlock, num), kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    launch_stage<true>(d_a, n, d_tabs, length, num, division, m, s);
     return hipGetLastError();
 }
 
 hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
                            hipStream_t s)
 {
-    gs_stage_kernel<<<dim3((n / 2 + kBlock - 1) / kBlock, num), kBlock, 0, s>>>(d_a, d_tabs, n, length, division, m);
+    launch_stage<false>(d_a, n, d_tabs, length, num, division, m, s);
     return hipGetLastError();
 }
 
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
                             const ModSet& m, hipStream_t s)
 {
-    dim3 grid((n + kBlock - 1) / kBlock, num);
-    pointwise_kernel<<<grid, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, m);
+    const bool vec = (n % 2 == 0) && ((((uintptr_t)d_c | (uintptr_t)d_a | (uintptr_t)d_b) & 15u) == 0);
+    unsigned bpp = ((vec ? n / 2 : n) + kBlock - 1) / kBlock;
+    if (bpp > 64) bpp = 64;                               // grid-stride inside the polynomial beyond that
+    while ((unsigned long long)bpp * num > 0x7fffffffull && bpp > 1) bpp /= 2;
+    if (vec) pointwise_kernel<true><<<bpp * num, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, bpp, m);
+    else pointwise_kernel<false><<<bpp * num, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, bpp, m);
     return hipGetLastError();
 }
 
 hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s)
 {
     pointwise_scalar_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(d_a, b, n, q, mu, k);
+    return hipGetLastError();
+}
+
+hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_flag, hipStream_t s)
+{
+    tables_differ_kernel<<<256, kBlock, 0, s>>>(d_x, d_y, n, count, d_flag);
+    return hipGetLastError();
+}
+
+hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s)
+{
+    tables_check_kernel<<<128, kBlock, 0, s>>>(d_x, d_y, n, count, d_guard, epoch);
     return hipGetLastError();
 }
 

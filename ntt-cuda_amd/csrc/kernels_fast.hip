@@ -19,15 +19,15 @@ namespace {
 // ---- pointwise c = a (.) b, 16 bytes per lane ----------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_pointwise(u64* __restrict__ c, const u64* __restrict__ a, const u64* __restrict__ b, unsigned n, unsigned division,
-            const PrimeDev* __restrict__ primes)
+            const PrimeDev* __restrict__ primes, unsigned bpp)
 {
-    const unsigned y = blockIdx.y;
+    const unsigned y = blockIdx.x / bpp, bx = blockIdx.x % bpp;      // (a one-dimensional grid: no 65535 limit on the batch)
     const PrimeDev p = primes[y % division];
     const size_t base = (size_t)y * n;
     const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a + base);
     const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b + base);
     ulonglong2* c2 = reinterpret_cast<ulonglong2*>(c + base);
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n / 2; i += gridDim.x * 256) {
+    for (unsigned i = bx * 256 + threadIdx.x; i < n / 2; i += bpp * 256) {
         const ulonglong2 x = a2[i], w = b2[i];
         ulonglong2 r;
         r.x = barrett_mul(x.x, w.x, p.q, p.mu, p.k);
@@ -143,7 +143,9 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
     hipError_t e;
     if ((e = hipMalloc((void**)&t->d_fwd, words * sizeof(TwPair))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&t->d_inv, words * sizeof(TwPair))) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&t->d_primes, num_primes * sizeof(PrimeDev))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&t->d_primes_alloc, (num_primes + 1) * sizeof(PrimeDev))) != hipSuccess) return e;
+    if ((e = hipMemset(t->d_primes_alloc, 0, sizeof(PrimeDev))) != hipSuccess) return e;          // guard words (kernels.hpp)
+    t->d_primes = static_cast<PrimeDev*>(t->d_primes_alloc) + 1;
     if ((e = hipMemcpy(t->d_fwd, hf.data(), words * sizeof(TwPair), hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(t->d_inv, hi.data(), words * sizeof(TwPair), hipMemcpyHostToDevice)) != hipSuccess) return e;
     if ((e = hipMemcpy(t->d_primes, pd.data(), num_primes * sizeof(PrimeDev), hipMemcpyHostToDevice)) != hipSuccess) return e;
@@ -154,7 +156,8 @@ void fast_tables_destroy(FastTables* t)
 {
     if (t->d_fwd) (void)hipFree(t->d_fwd);
     if (t->d_inv) (void)hipFree(t->d_inv);
-    if (t->d_primes) (void)hipFree(t->d_primes);
+    if (t->d_primes_alloc) (void)hipFree(t->d_primes_alloc);
+    t->d_primes_alloc = nullptr;
     t->d_fwd = t->d_inv = nullptr;
     t->d_primes = nullptr;
 }
@@ -196,8 +199,8 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
 {
     unsigned gx = (t.n / 2 + 255) / 256;
     if (gx > 64) gx = 64;
-    dim3 grid(gx, num);
-    k_pointwise<<<grid, 256, 0, s>>>(d_c, d_a, d_b, t.n, division, reinterpret_cast<const PrimeDev*>(t.d_primes));
+    while ((unsigned long long)gx * num > 0x7fffffffull && gx > 1) gx /= 2;
+    k_pointwise<<<gx * num, 256, 0, s>>>(d_c, d_a, d_b, t.n, division, reinterpret_cast<const PrimeDev*>(t.d_primes), gx);
     return hipGetLastError();
 }
 

@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
           unsigned prime_base, unsigned num)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
     const unsigned t = threadIdx.x;
@@ -80,6 +81,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
           unsigned prime_base, unsigned num)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
     const unsigned t = threadIdx.x;
@@ -189,6 +191,7 @@ __global__ void __launch_bounds__(1024, 4)
 k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
             unsigned prime_base, unsigned num)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
@@ -239,6 +242,7 @@ __global__ void __launch_bounds__(1024, 4)
 k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
             unsigned prime_base, unsigned num)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
@@ -364,6 +368,7 @@ __global__ void __launch_bounds__(64, 1)
 k_fwd15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
              unsigned prime_base)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     const unsigned y = blockIdx.x >> 4, t = ((blockIdx.x & 15u) << 6) | threadIdx.x;
@@ -382,6 +387,7 @@ __global__ void __launch_bounds__(64, 1)
 k_fwd15_rows(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
              unsigned prime_base)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
@@ -408,6 +414,7 @@ __global__ void __launch_bounds__(64, 1)
 k_inv15_rows(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
              unsigned prime_base)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
@@ -432,6 +439,7 @@ __global__ void __launch_bounds__(64, 1)
 k_inv15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
              unsigned prime_base)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     const unsigned y = blockIdx.x >> 4, t = ((blockIdx.x & 15u) << 6) | threadIdx.x;

@@ -87,6 +87,16 @@ struct PrimeDev {
     u32 pad_;
 };
 
+// Checked raw calls (kernels.hpp, kGuardBit): the record in front of the PrimeDev array holds {current epoch, epoch of the
+// last table mismatch}.  Returns true when this launch must not touch the data; clears the flag bit of prime_base.
+__device__ __forceinline__ bool guard_says_skip(const PrimeDev* primes, unsigned& prime_base)
+{
+    if (!(prime_base & 0x80000000u)) return false;
+    prime_base &= 0x7fffffffu;
+    const unsigned* g = reinterpret_cast<const unsigned*>(primes - 1);
+    return g[0] == g[1];
+}
+
 struct TwPair {       // {w, floor(w * 2^64 / q)}
     u64 w, wp;
 };

@@ -76,6 +76,9 @@ _SIGNATURES = {
     "mi355ntt_pointwise_mul": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
     "mi355ntt_pointwise_mul_scalar": (ctypes.c_int, [vp, vp, u64, ctypes.c_uint, vp]),
     "mi355ntt_polymul_batch": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_raw_cache_clear": (ctypes.c_int, []),
+    "mi355ntt_raw_uses_fast_kernels": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
+    "mi355ntt_raw_trust_tables": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
     "mi355ntt_forward_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, u64, u64, ctypes.c_int, vp]),
     "mi355ntt_inverse_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, u64, u64, ctypes.c_int, vp]),
     "mi355ntt_forward_batch_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, vp]),
@@ -356,6 +359,21 @@ class Moduli:
 
     def args(self):
         return self.q.ctypes.data_as(u64p), self.mu.ctypes.data_as(u64p), self.bits.ctypes.data_as(u32p)
+
+
+def raw_cache_clear():
+    """Forget every context the raw entry points derived from caller tables (include/mi355ntt.h, "Routing")."""
+    _check(lib().mi355ntt_raw_cache_clear(), "mi355ntt_raw_cache_clear")
+
+
+def raw_uses_fast_kernels(n, table, moduli, inverse=False):
+    """True when forwardNTT_batch / inverseNTT_batch with this table and these moduli run the throughput kernels."""
+    return bool(lib().mi355ntt_raw_uses_fast_kernels(int(n), _ptr(table), 1 if inverse else 0, int(moduli.q.size), *moduli.args()))
+
+
+def raw_trust_tables(n, table, moduli, inverse=False):
+    """The caller's promise that `table` keeps its contents: raw calls on it skip the per-call table comparison."""
+    return bool(lib().mi355ntt_raw_trust_tables(int(n), _ptr(table), 1 if inverse else 0, int(moduli.q.size), *moduli.args()))
 
 
 def forwardNTT_batch(device_a, n, psi_powers, num, division, moduli, stream=None):

@@ -16,36 +16,41 @@ def cost(op):
     op = re.sub(r'_(e32|e64|sdwa|dpp)$', '', op)
     if op.startswith('v_cmp'): return COST['v_cmp']
     return COST.get(op)
-lines = open(sys.argv[1]).read().split('\n')
-filt = sys.argv[2] if len(sys.argv) > 2 else ''
-kern, cur = {}, None
-for l in lines:
-    m = re.match(r'^(_Z\w+):', l)
-    if m: cur = m.group(1); kern[cur] = []; continue
-    if cur is not None:
-        kern[cur].append(l)
-        if 's_endpgm' in l: cur = None
-for name, body in kern.items():
-    if filt and filt not in name: continue
-    labels, best = {}, None
-    for i, l in enumerate(body):
-        m = re.match(r'^(\.LBB\d+_\d+):', l)
-        if m: labels[m.group(1)] = i
-        m = re.search(r's_cbranch_\w+ (\.LBB\d+_\d+)', l)
-        if m and m.group(1) in labels:
-            seg = [x.split()[0] for x in body[labels[m.group(1)]:i] if x.strip() and not x.strip().startswith((';', '.'))]
-            if best is None or len(seg) > len(best): best = seg
-    if not best: continue
-    c = collections.Counter(best)
-    tot, unknown, nv = 0.0, collections.Counter(), 0
-    for op, n in c.items():
-        if op.startswith('v_'):
-            nv += n
-            k = cost(op)
-            if k is None: unknown[op] += n; k = 4.1
-            tot += k * n
-    other = {k: n for k, n in c.items() if not k.startswith('v_')}
-    print('%s\n   loop: %d instr, %d VALU, VALU issue estimate %.0f cycles/wave  (x4 waves/SIMD = %.0f per polynomial)' % (name[:60], len(best), nv, tot, 4 * tot))
-    print('   VALU mix:', {k: n for k, n in c.most_common(40) if k.startswith('v_')})
-    print('   other   :', dict(sorted(other.items(), key=lambda x: -x[1])[:14]))
-    if unknown: print('   uncosted (taken as 4.1):', dict(unknown))
+def main():
+    lines = open(sys.argv[1]).read().split('\n')
+    filt = sys.argv[2] if len(sys.argv) > 2 else ''
+    kern, cur = {}, None
+    for l in lines:
+        m = re.match(r'^(_Z\w+):', l)
+        if m: cur = m.group(1); kern[cur] = []; continue
+        if cur is not None:
+            kern[cur].append(l)
+            if 's_endpgm' in l: cur = None
+    for name, body in kern.items():
+        if filt and filt not in name: continue
+        labels, best = {}, None
+        for i, l in enumerate(body):
+            m = re.match(r'^(\.LBB\d+_\d+):', l)
+            if m: labels[m.group(1)] = i
+            m = re.search(r's_cbranch_\w+ (\.LBB\d+_\d+)', l)
+            if m and m.group(1) in labels:
+                seg = [x.split()[0] for x in body[labels[m.group(1)]:i] if x.strip() and not x.strip().startswith((';', '.'))]
+                if best is None or len(seg) > len(best): best = seg
+        if not best: continue
+        c = collections.Counter(best)
+        tot, unknown, nv = 0.0, collections.Counter(), 0
+        for op, n in c.items():
+            if op.startswith('v_'):
+                nv += n
+                k = cost(op)
+                if k is None: unknown[op] += n; k = 4.1
+                tot += k * n
+        other = {k: n for k, n in c.items() if not k.startswith('v_')}
+        print('%s\n   loop: %d instr, %d VALU, VALU issue estimate %.0f cycles/wave  (x4 waves/SIMD = %.0f per polynomial)' % (name[:60], len(best), nv, tot, 4 * tot))
+        print('   VALU mix:', {k: n for k, n in c.most_common(40) if k.startswith('v_')})
+        print('   other   :', dict(sorted(other.items(), key=lambda x: -x[1])[:14]))
+        if unknown: print('   uncosted (taken as 4.1):', dict(unknown))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r02.json (read by bench.py).
+
+Compiles ntt-cuda_amd/csrc/kernels_fast_n15.hip to gfx950 assembly, sums the measured steady-state issue cost
+(tools/ubench_issue.hip, profiles/r02_ubench_issue_costs.txt) over the instructions of each kernel's polynomial loop
+and converts to transforms/s: one polynomial per CU at a time, 4 waves per SIMD, 256 CUs, the in-kernel clock the
+chip holds under this load (2.35 GHz, profiles/r02_*: s_memtime / s_memrealtime).  Run here (no GPU needed)."""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_cost  # noqa: E402  (prints nothing on import: guarded below)
+
+CLOCK_HZ, CUS = 2.35e9, 256
+
+
+def loop_cost(lines, name_part):
+    kern, cur = {}, None
+    for l in lines:
+        m = re.match(r'^(_Z\w+):', l)
+        if m:
+            cur = m.group(1)
+            kern[cur] = []
+            continue
+        if cur is not None:
+            kern[cur].append(l)
+            if 's_endpgm' in l:
+                cur = None
+    for name, body in kern.items():
+        if name_part not in name:
+            continue
+        labels, best = {}, None
+        for i, l in enumerate(body):
+            m = re.match(r'^(\.LBB\d+_\d+):', l)
+            if m:
+                labels[m.group(1)] = i
+            m = re.search(r's_cbranch_\w+ (\.LBB\d+_\d+)', l)
+            if m and m.group(1) in labels:
+                seg = [x.split()[0] for x in body[labels[m.group(1)]:i] if x.strip() and not x.strip().startswith((';', '.'))]
+                if best is None or len(seg) > len(best):
+                    best = seg
+        tot, nv = 0.0, 0
+        for op in best:
+            if op.startswith('v_'):
+                nv += 1
+                k = isa_cost.cost(op)
+                tot += 4.1 if k is None else k
+        return tot, nv, len(best)
+    raise SystemExit("kernel %s not found" % name_part)
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "n15.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "ntt-cuda_amd", "csrc"),
+                               "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
+                               os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip"), "-o", out], stderr=subprocess.DEVNULL)
+        lines = open(out).read().split('\n')
+    res = {}
+    for k, sym in (("k_forward15", "k_forward15ILi4ELb1"), ("k_inverse15", "k_inverse15ILi4ELb1")):
+        cyc, nv, ni = loop_cost(lines, sym)
+        per_poly = 4 * cyc                                    # 4 waves share a SIMD
+        res[k] = {"valu_issue_cycles_per_wave": cyc, "valu_instructions_per_wave": nv, "loop_instructions": ni,
+                  "cycles_per_polynomial_per_cu": per_poly, "transforms_per_s": CUS * CLOCK_HZ / per_poly}
+    res["pairs_per_s"] = 1.0 / (1.0 / res["k_forward15"]["transforms_per_s"] + 1.0 / res["k_inverse15"]["transforms_per_s"])
+    res["source"] = ("tools/valu_ceiling.py: measured steady-state issue cycles per instruction (profiles/r02_ubench_issue_costs.txt) summed "
+                     "over the polynomial loop of the shipped <HL 4, near-2^k> kernels, 4 waves per SIMD, %d CUs at %.2f GHz in-kernel clock; "
+                     "the bare butterfly stream measures 11.1 M transforms/s (profiles/r02_ubench_butterfly_ceiling.txt)" % (CUS, CLOCK_HZ / 1e9))
+    path = os.path.join(ROOT, "profiles", "valu_ceiling_r02.json")
+    json.dump(res, open(path, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
