@@ -149,6 +149,19 @@ def _ptr(t):
     return vp(t.data_ptr())
 
 
+def _ptr_n(t, words, device=None):
+    """Device pointer of a tensor that must hold at least `words` 64-bit words (and live on `device`, if given): the C ABI
+    takes plain pointers, so a short view or a tensor of another GPU would be silent out-of-bounds traffic."""
+    if isinstance(t, int):
+        return vp(t)
+    assert t.is_cuda and t.is_contiguous() and t.element_size() == 8, "need a contiguous 64-bit CUDA tensor"
+    if t.numel() < words:
+        raise ValueError("tensor holds %d words, the call addresses %d" % (t.numel(), words))
+    if device is not None and t.device.index != device:
+        raise ValueError("tensor is on cuda:%s, the context on cuda:%d" % (t.device.index, device))
+    return vp(t.data_ptr())
+
+
 def _byte_ptr(t):
     assert t.is_cuda and t.is_contiguous() and t.element_size() == 1, "need a contiguous byte CUDA tensor"
     return vp(t.data_ptr())
@@ -295,38 +308,41 @@ class NTTContext:
         return int(lib().mi355ntt_ctx_psiinv_tables(self._h) or 0)
 
     # forwardNTT / inverseNTT (ntt_60bit.cuh:314,350)
+    def _p(self, t, polys=1):
+        return _ptr_n(t, int(polys) * self.n, self.device)
+
     def forward(self, a, prime_idx=0, stream=None):
-        _check(lib().mi355ntt_forward(self._h, _ptr(a), int(prime_idx), _stream(stream)), "mi355ntt_forward")
+        _check(lib().mi355ntt_forward(self._h, self._p(a), int(prime_idx), _stream(stream)), "mi355ntt_forward")
 
     def inverse(self, a, prime_idx=0, stream=None):
-        _check(lib().mi355ntt_inverse(self._h, _ptr(a), int(prime_idx), _stream(stream)), "mi355ntt_inverse")
+        _check(lib().mi355ntt_inverse(self._h, self._p(a), int(prime_idx), _stream(stream)), "mi355ntt_inverse")
 
     def forward_double(self, a, b, prime_idx=0, stream1=None, stream2=None):
-        _check(lib().mi355ntt_forward_double(self._h, _ptr(a), _ptr(b), int(prime_idx), _stream(stream1), _stream(stream2)),
+        _check(lib().mi355ntt_forward_double(self._h, self._p(a), self._p(b), int(prime_idx), _stream(stream1), _stream(stream2)),
                "mi355ntt_forward_double")
 
     # forwardNTT_batch / inverseNTT_batch (ntt_60bit.cuh:608,652)
     def forward_batch(self, a, num, division=None, stream=None):
-        _check(lib().mi355ntt_forward_batch(self._h, _ptr(a), int(num), int(division or self.num_primes), _stream(stream)),
+        _check(lib().mi355ntt_forward_batch(self._h, self._p(a, num), int(num), int(division or self.num_primes), _stream(stream)),
                "mi355ntt_forward_batch")
 
     def inverse_batch(self, a, num, division=None, stream=None):
-        _check(lib().mi355ntt_inverse_batch(self._h, _ptr(a), int(num), int(division or self.num_primes), _stream(stream)),
+        _check(lib().mi355ntt_inverse_batch(self._h, self._p(a, num), int(num), int(division or self.num_primes), _stream(stream)),
                "mi355ntt_inverse_batch")
 
     # barrett / barrett_batch / barrett_batch_3param (poly_arithmetic.cuh:9-98)
     def pointwise_mul(self, c, a, b, num, division=None, stream=None):
-        _check(lib().mi355ntt_pointwise_mul(self._h, _ptr(c), _ptr(a), _ptr(b), int(num), int(division or self.num_primes),
-                                            _stream(stream)), "mi355ntt_pointwise_mul")
+        _check(lib().mi355ntt_pointwise_mul(self._h, self._p(c, num), self._p(a, num), self._p(b, num), int(num),
+                                            int(division or self.num_primes), _stream(stream)), "mi355ntt_pointwise_mul")
 
     # barrett_int (poly_arithmetic.cuh:100)
     def pointwise_mul_scalar(self, a, b, prime_idx=0, stream=None):
-        _check(lib().mi355ntt_pointwise_mul_scalar(self._h, _ptr(a), int(b), int(prime_idx), _stream(stream)),
+        _check(lib().mi355ntt_pointwise_mul_scalar(self._h, self._p(a), int(b), int(prime_idx), _stream(stream)),
                "mi355ntt_pointwise_mul_scalar")
 
     # forwardNTT_batch -> barrett_batch -> inverseNTT_batch (bfv_encryption.cuh:268-271), fused
     def polymul_batch(self, a, bhat, num, division=None, stream=None):
-        _check(lib().mi355ntt_polymul_batch(self._h, _ptr(a), _ptr(bhat), int(num), int(division or self.num_primes),
+        _check(lib().mi355ntt_polymul_batch(self._h, self._p(a, num), self._p(bhat, num), int(num), int(division or self.num_primes),
                                             _stream(stream)), "mi355ntt_polymul_batch")
 
 
@@ -378,14 +394,14 @@ def raw_trust_tables(n, table, moduli, inverse=False):
 
 def forwardNTT_batch(device_a, n, psi_powers, num, division, moduli, stream=None):
     """ntt_60bit.cuh:608 (+ the moduli the reference reads from __constant__ memory)"""
-    _check(lib().mi355ntt_forward_batch_raw(_ptr(device_a), int(n), _ptr(psi_powers), int(num), int(division), *moduli.args(),
-                                            _stream(stream)), "forwardNTT_batch")
+    _check(lib().mi355ntt_forward_batch_raw(_ptr_n(device_a, int(num) * int(n)), int(n), _ptr_n(psi_powers, int(division) * int(n)), int(num),
+                                            int(division), *moduli.args(), _stream(stream)), "forwardNTT_batch")
 
 
 def inverseNTT_batch(device_a, n, psiinv_powers, num, division, moduli, stream=None):
     """ntt_60bit.cuh:652"""
-    _check(lib().mi355ntt_inverse_batch_raw(_ptr(device_a), int(n), _ptr(psiinv_powers), int(num), int(division), *moduli.args(),
-                                            _stream(stream)), "inverseNTT_batch")
+    _check(lib().mi355ntt_inverse_batch_raw(_ptr_n(device_a, int(num) * int(n)), int(n), _ptr_n(psiinv_powers, int(division) * int(n)), int(num),
+                                            int(division), *moduli.args(), _stream(stream)), "inverseNTT_batch")
 
 
 def barrett(a, b, q, mu, qbit, stream=None):

@@ -43,6 +43,12 @@ class BFVContext:
                                          ps.ctypes.data_as(u64p), int(t), int(gamma), int(device),
                                          CTX_EXACT_ON_INEXACT_PRIMES if exact_on_inexact_primes else 0), "mi355ntt_bfv_create")
         self.n, self.num_primes, self.t, self.gamma = int(n), int(qs.size), int(t), int(gamma)
+        self.device = int(device)
+
+    def _p(self, t, polys):
+        """pointer of a buffer that must hold `polys` polynomials on this object's device (the C ABI takes raw pointers)"""
+        from . import _ptr_n
+        return _ptr_n(t, int(polys) * self.n, self.device)
 
     def close(self):
         from . import lib, vp
@@ -74,16 +80,21 @@ class BFVContext:
 
     def keygen(self, secret_key, public_key, e, stream=None):
         from . import lib, _check, _ptr, _stream
-        _check(lib().mi355ntt_bfv_keygen(self._h, _ptr(secret_key), _ptr(public_key), _ptr(e), _stream(stream)), "mi355ntt_bfv_keygen")
+        R = self.num_primes
+        _check(lib().mi355ntt_bfv_keygen(self._h, self._p(secret_key, R), self._p(public_key, 2 * R), self._p(e, R), _stream(stream)),
+               "mi355ntt_bfv_keygen")
 
     def encrypt(self, c, public_key, e, m, stream=None):
         from . import lib, _check, _ptr, _stream
-        _check(lib().mi355ntt_bfv_encrypt(self._h, _ptr(c), _ptr(public_key), _ptr(e), _ptr(m), _stream(stream)), "mi355ntt_bfv_encrypt")
+        R = self.num_primes
+        _check(lib().mi355ntt_bfv_encrypt(self._h, self._p(c, 2 * R), self._p(public_key, 2 * R), self._p(e, 2 * R), self._p(m, 1),
+                                          _stream(stream)), "mi355ntt_bfv_encrypt")
 
     def decrypt(self, c, secret_key, stream=None):
         """In place on c; returns the view of c holding the plaintext (c + n (num_primes - 2))."""
         from . import lib, _check, _ptr, _stream
-        _check(lib().mi355ntt_bfv_decrypt(self._h, _ptr(c), _ptr(secret_key), _stream(stream)), "mi355ntt_bfv_decrypt")
+        R = self.num_primes
+        _check(lib().mi355ntt_bfv_decrypt(self._h, self._p(c, 2 * R), self._p(secret_key, R - 1), _stream(stream)), "mi355ntt_bfv_decrypt")
         off = self.n * (self.num_primes - 2)
         return c.reshape(-1)[off: off + self.n]
 

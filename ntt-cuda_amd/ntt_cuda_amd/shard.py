@@ -125,9 +125,9 @@ def scatter_transform_gather(full, num, n, division, transform, chunks=4, src=0,
             reqs = dist.batch_isend_irecv(ops) if ops else []
             if 0 <= k - 1 < len(pieces[src]):                        # the root's own piece k - 1 meanwhile
                 s, c = pieces[src][k - 1]
-                piece = full[s:s + c].clone()
+                piece = out[s:s + c]                                   # contiguous rows of the result: transform in place there
+                piece.copy_(full[s:s + c])
                 transform(piece, c)
-                out[s:s + c] = piece
             for q in reqs:
                 q.wait()
         return out
@@ -140,11 +140,12 @@ def scatter_transform_gather(full, num, n, division, transform, chunks=4, src=0,
         if 0 <= k - 2 < len(mine):
             ops.append(dist.P2POp(dist.isend, bufs[k - 2], src, group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        # piece k - 1 arrived in round k - 1 (waited for at the end of that round): transform it while k arrives and k - 2 leaves
+        # piece k - 1 arrived in round k - 1 (waited for at the end of that round): transform it while k arrives and k - 2
+        # leaves.  No host synchronisation: the transform is enqueued on the current stream, and the backend orders the send
+        # of round k + 1 behind it (RCCL work is launched on a stream that waits for the current stream's tail; work.wait()
+        # makes the current stream wait for the transfer) -- the hand-off is stream-ordered, event based.
         if 0 <= k - 1 < len(mine):
             transform(bufs[k - 1], mine[k - 1][1])
-            if bufs[k - 1].is_cuda:
-                torch.cuda.current_stream().synchronize()            # the result must be complete before round k + 1 sends it
         for q in reqs:
             q.wait()
     return None
