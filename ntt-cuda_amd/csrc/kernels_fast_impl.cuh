@@ -57,8 +57,13 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     unsigned y = blockIdx.x;
     MI355NTT_STAMP(15);
     load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
-    for (; y < num; y += gridDim.x) {
-        const unsigned idx = prime_base + y % division;
+    // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
+    // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
+    // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+    for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
+        const unsigned idx = prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         u64* poly = a + (size_t)y * G::N;
@@ -89,8 +94,13 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     unsigned y = blockIdx.x;
     MI355NTT_STAMP(15);
     load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
-    for (; y < num; y += gridDim.x) {
-        const unsigned idx = prime_base + y % division;
+    // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
+    // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
+    // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+    for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
+        const unsigned idx = prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         u64* poly = a + (size_t)y * G::N;
@@ -124,11 +134,7 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 #define MI355NTT_PRIO_I2 0
 #define MI355NTT_PRIO_I3 2
 #endif
-#if MI355NTT_DYNPRIO
-#define MI355NTT_SETPRIO(x)
-#else
 #define MI355NTT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 // optional second priority inside a round: from scheduling group PSPLIT on (-1 = none) the wave runs at priority ..B
 #ifndef MI355NTT_PSPLIT_R1
 #define MI355NTT_PSPLIT_R1 -1
@@ -195,41 +201,56 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    u64* slice = lds + wave * WAVE_SLICE_WORDS;
+    // Thread-derived values are rebuilt where they are used -- the wave index lives in an SGPR, the lane index comes from
+    // v_mbcnt -- instead of surviving the polynomial loop in VGPRs the kernel does not have (they were its spills, reloaded
+    // from scratch in front of the exchange and of the row store).
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+s"(wave_s));
+    auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_FWD>();
     MI355NTT_WGSTAMP(1);
-    load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, t);
+    load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, fresh_t());
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
-    for (; y < num; y += gridDim.x) {
-        const unsigned idx = prime_base + y % division;
+    // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
+    // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
+    // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+    for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
+        const unsigned idx = prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
         u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
-        MI355NTT_STAMP2(it, 0);
+        MI355NTT_STAMPV(0, 0);
+#if defined(MI355NTT_STAMPS) && MI355NTT_STAMPS == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostic build only: separates the load wait from round 1
+        MI355NTT_STAMPV(-1, 1);
+#endif
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
-        ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, t, p);
-        MI355NTT_STAMP2(it, 1);
+        ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, 0u, p);   // (round 1 reads no thread-derived value)
+        MI355NTT_STAMPV(1, 2);
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
-        MI355NTT_STAMP2(it, 2);
-        exchange<LOGN, 10, 5>(v, lds, t);
-        MI355NTT_STAMP2(it, 3);
+        MI355NTT_STAMPV(2, -1);
+        exchange<LOGN, 10, 5>(v, lds, fresh_t());
+        MI355NTT_STAMPV(3, 3);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
-        ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, t, p);
-        MI355NTT_STAMP2(it, 4);
-        wave_transpose_5_to_0(v, slice, lane);
+        ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, fresh_t(), p);
+        MI355NTT_STAMPV(4, -1);
+        wave_transpose_5_to_0(v, lds + wave_s * WAVE_SLICE_WORDS, fresh_lane_id());
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
-        ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, t, p);
+        ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
-        MI355NTT_STAMP2(it, 5);
-        wave_store_rows(v, slice, make_rsrc(poly, G::N * 8u), wave * 16384u, lane);
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, t);
-        MI355NTT_STAMP2(it, 6);
+        MI355NTT_STAMPV(5, 4);
+        // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic instead of a VGPR kept live across the loop)
+        wave_store_rows(v, lds + wave_s * WAVE_SLICE_WORDS, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
+        MI355NTT_STAMPV(-1, 5);
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, fresh_t());
+        MI355NTT_STAMPV(6, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
     }
@@ -254,15 +275,20 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_INV>();
     MI355NTT_WGSTAMP(1);
-    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, G::N * 8u), wave * 16384u, lane);
+    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u), 0u, lane);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
-    for (; y < num; y += gridDim.x) {
+    // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
+    // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
+    // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+    for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
         unsigned t = t0;
         asm volatile("" : "+v"(t));      // thread-derived offsets are recomputed per polynomial, not kept live across the loop
         const unsigned lane = t & 63u, wave = t >> 6;
         u64* slice = lds + wave * WAVE_SLICE_WORDS;
-        const unsigned idx = prime_base + y % division;
+        const unsigned idx = prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
@@ -285,7 +311,8 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         MI355NTT_STAMP2(it, 5);
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num)
-            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, G::N * 8u), wave * 16384u, lane);
+            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u),
+                           0u, lane);
         MI355NTT_STAMP2(it, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
@@ -308,8 +335,13 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     unsigned y = blockIdx.x;
     stagger_start<MI355NTT_STAGGER_MUL>();
     load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
-    for (; y < num; y += gridDim.x) {
-        const unsigned idx = y % division;
+    // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
+    // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
+    // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+    for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
+        const unsigned idx = ymod;
         const PrimeDev p = primes[idx];
         const TwPair* tf = twf + (size_t)idx * G::N;
         const TwPair* ti = twi + (size_t)idx * G::N;

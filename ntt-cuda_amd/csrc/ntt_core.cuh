@@ -55,6 +55,9 @@ __device__ __forceinline__ unsigned long long stamp_real()
     return tm;
 }
 #define MI355NTT_STAMP_DECL StampAcc sacc; sacc.prev = stamp_now(); for (int k_ = 0; k_ < 8; k_++) sacc.sum[k_] = 0; unsigned long long real0_ = stamp_real(), clk0_ = sacc.prev;
+// MI355NTT_STAMPS == 2: a second slot assignment of the forward kernel that resolves the end of the iteration (wait for the
+// loaded polynomial / round 1 / exchange / rounds 2+3 / row store / next loads): MI355NTT_STAMPV(slot in layout 1, in layout 2), -1 = no mark
+#define MI355NTT_STAMPV(s1, s2) { if ((MI355NTT_STAMPS == 2 ? (s2) : (s1)) >= 0) MI355NTT_STAMP2(0, (MI355NTT_STAMPS == 2 ? (s2) : (s1))) }
 #define MI355NTT_STAMP2(it, slot) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = stamp_now(); sacc.sum[slot] += n_ - sacc.prev; sacc.prev = n_; __builtin_amdgcn_sched_barrier(0); }
 #define MI355NTT_STAMP_FLUSH { unsigned long long real1_ = stamp_real(), clk1_ = stamp_now(); sacc.sum[7] = ((clk1_ - clk0_) << 24) / (real1_ - real0_ + 1); /* shader cycles per 100 MHz tick, x 2^24 */ \
     if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 8; k_++) g_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k_] = sacc.sum[k_]; } }
@@ -64,6 +67,7 @@ __device__ unsigned long long* g_wg_buf;
 #define MI355NTT_WGSTAMP(slot) { if (threadIdx.x == 0) g_wg_buf[(size_t)blockIdx.x * 8 + (slot)] = stamp_real(); }
 #define MI355NTT_STAMP(slot)
 #else
+#define MI355NTT_STAMPV(s1, s2)
 #define MI355NTT_WGSTAMP(slot)
 #define MI355NTT_STAMP(slot)
 #define MI355NTT_STAMP2(it, slot)
@@ -508,10 +512,20 @@ __device__ __forceinline__ void wave_transpose_0_to_5(u64 (&v)[32], u64* slice, 
 // instead of being hoisted out of the polynomial loop and spilled.
 __device__ __forceinline__ unsigned row_swz(unsigned row) { return (row >> 1) & 7u; }
 
-__device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, BufRsrc dst, unsigned wave_byte_off, unsigned lane)
+// Lane index from the execution mask (v_mbcnt_lo/hi: two instructions, no register kept live).  The callers below take it
+// fresh each time: the thread index would otherwise have to survive the whole polynomial loop in a VGPR the kernels do not
+// have (it was one of their spills, reloaded from scratch in front of the row store).
+__device__ __forceinline__ unsigned fresh_lane_id()
+{
+    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));          // opaque: recomputed at every use site instead of being hoisted out of the loop
+    return l;
+}
+
+__device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, BufRsrc dst, unsigned wave_byte_off, unsigned)
 {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(lane));
+    const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     static_for<2>([&](auto cc) {
@@ -536,9 +550,9 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
 
 // one column half (CH = 0/1): 16 words of this lane's row into out[0..15]
 template <int CH>
-__device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
+__device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned)
 {
-    asm volatile("" : "+v"(lane));
+    const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     v4u32 x[8];
@@ -565,9 +579,9 @@ __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, 
 #ifndef MI355NTT_INV_MERGED_LOADS
 #define MI355NTT_INV_MERGED_LOADS 0
 #endif
-__device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
+__device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned)
 {
-    asm volatile("" : "+v"(lane));
+    const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     v4u32 x[16];
@@ -665,56 +679,16 @@ __device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* 
 // ------------------------------------------------------------------------------------------------
 // wave-priority hooks of the n = 2^15 kernels (s_setprio; priority outranks age in the SIMD's issue arbitration)
 // ------------------------------------------------------------------------------------------------
-// Static form: a round may lower the wave's priority from group PSPLIT on (the phases of a polynomial get descending
-// priorities so that the waves that are behind win the issue slots and all 16 reach the workgroup exchange together).
-// Dynamic form (MI355NTT_DYNPRIO = log2 of the time slice in shader cycles, 0 = off): every group start the wave sets
-// priority ((s_memtime >> SLICE) + rank of the wave on its SIMD) & 3, i.e. the four waves of a SIMD take turns at the
-// top priority -- round-robin time slicing on top of the hardware's oldest-first arbitration.
-#ifndef MI355NTT_DYNPRIO
-#define MI355NTT_DYNPRIO 0
-#endif
-__device__ __forceinline__ void dyn_prio_tick(unsigned t)
-{
-#if MI355NTT_DYNPRIO
-    // One opaque asm block (s_setprio takes an immediate, so the four cases are a compare ladder; as C++ branches they would
-    // split the straight-line round into basic blocks and wreck its register allocation).
-    const unsigned slot = __builtin_amdgcn_readfirstlane(t >> 8);            // waves w, w+4, w+8, w+12 share a SIMD
-    unsigned long long tm;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
-    const unsigned p = ((unsigned)(tm >> MI355NTT_DYNPRIO) + slot) & 3u;
-    asm volatile("s_cmp_lg_u32 %0, 0\n\t"
-                 "s_cbranch_scc1 1f\n\t"
-                 "s_setprio 0\n\t"
-                 "s_branch 4f\n"
-                 "1:\n\t"
-                 "s_cmp_lg_u32 %0, 1\n\t"
-                 "s_cbranch_scc1 2f\n\t"
-                 "s_setprio 1\n\t"
-                 "s_branch 4f\n"
-                 "2:\n\t"
-                 "s_cmp_lg_u32 %0, 2\n\t"
-                 "s_cbranch_scc1 3f\n\t"
-                 "s_setprio 2\n\t"
-                 "s_branch 4f\n"
-                 "3:\n\t"
-                 "s_setprio 3\n"
-                 "4:"
-                 :
-                 : "s"(p)
-                 : "scc", "memory");
-#else
-    (void)t;
-#endif
-}
+// A round may lower the wave's priority from scheduling group PSPLIT on: the phases of a polynomial get descending
+// priorities so that the waves that are behind win the issue slots and the 16 waves reach the workgroup exchange closer
+// together.  (Round 2 measured a time-sliced rotation of the priorities as well -- priority ((s_memtime >> k) + rank of the
+// wave on its SIMD) & 3, re-evaluated every group: a wave that is starved never reaches the instruction that would raise
+// its priority, the youngest wave of each SIMD fell further behind and the inverse lost 8 %:
+// profiles/r02_priority_schemes_wg_timeline.txt, dyn8..dyn13.)
 template <int PSPLIT, int PAFTER, int G>
-__device__ __forceinline__ void prio_hook(unsigned t)
+__device__ __forceinline__ void prio_hook(unsigned)
 {
-#if MI355NTT_DYNPRIO
-    if constexpr (PSPLIT != -2) dyn_prio_tick(t);
-#else
     if constexpr (PSPLIT >= 0 && G == PSPLIT) __builtin_amdgcn_s_setprio(PAFTER);
-    (void)t;
-#endif
 }
 
 #ifndef MI355NTT_MAD_CHAIN

@@ -82,7 +82,11 @@ int main(int argc, char** argv)
             unsigned nb = num < 256 ? num : 256;
             std::vector<unsigned long long> st((size_t)nb * 16 * 8);
             CK(hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost));
+#if MI355NTT_STAMPS == 2
+            const char* nmf[] = {"(loop top)", "wait for the loaded polynomial", "R1", "sync + exchange 10->5", "R2 + T5->0 + R3 + canon", "row store (both halves)", "issue next loads", "-"};
+#else
             const char* nmf[] = {"(loop top)", "R1 incl. load wait", "wait at sync", "exchange 10->5", "R2", "T5->0 + R3 + canon", "row store + issue next loads", "-"};
+#endif
             // inverse15: 0 loop top, 1 R1' (bit 0 round), 2 T0->5 + R2', 3 wait at sync, 4 exchange 5->10, 5 R3' + canon, 6 store + next row loads (waited for)
             const char* nmi[] = {"(loop top)", "R1'", "T0->5 + R2'", "wait at sync", "exchange 5->10", "R3' + canon", "store + next row loads (incl. wait)", "-"};
             const char** nm = which == 0 ? nmf : nmi;

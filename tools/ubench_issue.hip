@@ -64,6 +64,11 @@ __global__ void __launch_bounds__(1024) k_issue(Out* out, unsigned long long win
                 if constexpr (OP == 29) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[u]) : "v"(b));
                 if constexpr (OP == 30) asm volatile("v_mad_u32_u16 %0, %0, %1, %2" : "+v"(a[u]) : "v"(b), "v"(c));
                 if constexpr (OP == 31) asm volatile("v_dot2_u32_u16 %0, %0, %1, %2" : "+v"(a[u]) : "v"(b), "v"(c));
+                if constexpr (OP == 32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[u]), "+v"(a2[u]));
+                if constexpr (OP == 33) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[u]));
+                if constexpr (OP == 34) asm volatile("v_not_b32 %0, %0" : "+v"(a[u]));
+                if constexpr (OP == 35) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(a[u]));
+                if constexpr (OP == 36) asm volatile("v_cmp_ge_u64 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc\n\tv_cndmask_b32 %4, %4, %3, vcc" : "+v"(l[u]), "+v"(b64), "+v"(a[u]), "+v"(b), "+v"(a2[u]) : : "vcc");
             }
         }
         n += 16 * CH;
@@ -130,6 +135,8 @@ int main(int argc, char** argv)
         {"v_mov_b32", k_issue<12>, 1}, {"v_mad_u32_u24", k_issue<13>, 1}, {"v_mul_u32_u24", k_issue<14>, 1}, {"v_mul_hi_u32_u24", k_issue<17>, 1},
         {"v_alignbit_b32", k_issue<15>, 1}, {"v_lshlrev_b64", k_issue<16>, 1}, {"v_fma_f64", k_issue<19>, 1},
         {"v_pk_add_u16", k_issue<29>, 1}, {"v_mad_u32_u16", k_issue<30>, 1}, {"v_dot2_u32_u16", k_issue<31>, 1},
+        {"v_permlane32_swap_b32", k_issue<32>, 1}, {"v_mov_b32_dpp quad_perm", k_issue<33>, 1}, {"v_not_b32", k_issue<34>, 1},
+        {"v_ashrrev_i32", k_issue<35>, 1}, {"v_cmp_ge_u64 + 2 v_cndmask (triple)", k_issue<36>, 1},
     };
     printf("# shader cycles per wave-instruction per SIMD (pairs count as one), 1..4 waves per SIMD, %llu us windows\n", win);
     for (auto& o : ops) run(o.n, o.k, o.per, win);
