@@ -188,7 +188,13 @@ int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi35
 /* ------------------------------------------------------------------------------------------------
  * The reference's 30-bit path (old/ntt_30bit.cuh): 32-bit words, q < 2^30, the caller's mu
  * (floor(2^(2 bits) / q), old/30bit_ntt_test.cu:47-48) and 32-bit psi tables.  Same argument lists as the reference's
- * launchers; the _batch_ forms take `num` polynomials of the same prime.  n in {2048 .. 32768}.
+ * launchers; the _batch_ forms take `num` polynomials of the same prime.  n in {2048 .. 65536} (the reference's forwardNTT /
+ * inverseNTT dispatch N = 2048 ... 65536, old/ntt_30bit.cuh:271-283,321-405).
+ * Routing: with the canonical mu / bit_length and a modulus on which the single-subtraction Barrett is exact the calls run
+ * the native kernels (32 coefficients per thread in registers, lazy 32-bit Shoup butterflies; the companions of the CALLER's
+ * table are recomputed on the device in front of every call, so the transform always follows the table passed; a table
+ * entry >= q sends the call to the literal kernels on the device side); otherwise the literal kernels (the reference's
+ * butterflies with the caller's mu).  n = 2^16: one stage in memory + two 2^15 transforms.
  * ---------------------------------------------------------------------------------------------- */
 int mi355ntt_forward30_raw(mi355ntt_u32* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u32 q, mi355ntt_u32 mu, int bit_length,
                            const mi355ntt_u32* d_psi_table);                                       /* forwardNTT, :321-359 */

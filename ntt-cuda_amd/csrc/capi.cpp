@@ -650,9 +650,22 @@ int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi35
 static int check30(const void* a, const void* tab, unsigned n, mi355ntt_u32 q, int bits)
 {
     if (!a || !tab) return MI355NTT_EINVAL;
-    if (!is_pow2(n) || n < 2048 || n > 32768) return MI355NTT_EUNSUPPORTED;      /* forwardNTT dispatch, old/ntt_30bit.cuh:321-359 */
+    if (!is_pow2(n) || n < 2048 || n > 65536) return MI355NTT_EUNSUPPORTED;      /* forwardNTT dispatch, old/ntt_30bit.cuh:271-283,321-359 */
     if (bits < 3 || bits > 30 || q < 3 || (q >> bits) != 0) return MI355NTT_EUNSUPPORTED;
     return MI355NTT_OK;
+}
+
+/* m^-1 mod q when a 30-bit call may take the native kernels (the caller's mu and bit_length are the canonical ones and the
+ * reference's single-subtraction Barrett is exact for q, so the exact transform is the reference's words), else 0 */
+static unsigned ninv30_if_native(unsigned n, mi355ntt_u32 q, mi355ntt_u32 mu, int bits)
+{
+    static const bool literal_only = [] { const char* e = std::getenv("MI355NTT_RAW_LITERAL"); return e && e[0] && e[0] != '0'; }();
+    if (literal_only || !(q & 1u) || (unsigned)bits != bit_length(q)) return 0;
+    const u64 mu_ref = (((u128)1) << (2 * bits)) / q;
+    if (mu_ref != (u64)mu || !barrett_single_subtraction_exact(q, (unsigned)bits, mu_ref)) return 0;
+    const unsigned m = n == 65536 ? n / 2 : n;
+    if (m % q == 0) return 0;
+    return (unsigned)modinv(m % q, q);
 }
 
 int mi355ntt_forward30_batch_raw(mi355ntt_u32* d_a, unsigned n, const mi355ntt_u32* d_psi_table, unsigned num, mi355ntt_u32 q,
@@ -661,7 +674,8 @@ int mi355ntt_forward30_batch_raw(mi355ntt_u32* d_a, unsigned n, const mi355ntt_u
     int rc = check30(d_a, d_psi_table, n, q, bits);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
-    HIP_TRY(ntt30_forward(d_a, n, d_psi_table, num, q, mu, bits, (hipStream_t)s));
+    (void)hipGetLastError();
+    HIP_TRY(ntt30_forward(d_a, n, d_psi_table, num, q, mu, bits, ninv30_if_native(n, q, mu, bits), (hipStream_t)s));
     return MI355NTT_OK;
 }
 
@@ -671,7 +685,8 @@ int mi355ntt_inverse30_batch_raw(mi355ntt_u32* d_a, unsigned n, const mi355ntt_u
     int rc = check30(d_a, d_psiinv_table, n, q, bits);
     if (rc) return rc;
     if (num == 0) return MI355NTT_OK;
-    HIP_TRY(ntt30_inverse(d_a, n, d_psiinv_table, num, q, mu, bits, (hipStream_t)s));
+    (void)hipGetLastError();
+    HIP_TRY(ntt30_inverse(d_a, n, d_psiinv_table, num, q, mu, bits, ninv30_if_native(n, q, mu, bits), (hipStream_t)s));
     return MI355NTT_OK;
 }
 

@@ -69,8 +69,11 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
 hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s);
 
 // ---- the reference's 30-bit path (kernels_ntt30.hip): 32-bit words, single prime, `num` polynomials of n words ----
-hipError_t ntt30_forward(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s);
-hipError_t ntt30_inverse(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s);
+// ninv_native: m^-1 mod q (m = n, or n / 2 at n = 2^16) when the call may run the native kernels, 0 = literal kernels only
+hipError_t ntt30_forward(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, unsigned ninv_native,
+                         hipStream_t s);
+hipError_t ntt30_inverse(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, unsigned ninv_native,
+                         hipStream_t s);
 hipError_t ntt30_barrett(unsigned* d_a, const unsigned* d_b, size_t count, unsigned q, unsigned mu, int bits, hipStream_t s);
 
 }  // namespace mi355ntt

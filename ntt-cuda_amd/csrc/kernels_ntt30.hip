@@ -1,10 +1,26 @@
-// kernels_ntt30.hip -- the reference's 30-bit path (old/ntt_30bit.cuh): 32-bit coefficients, products
-// in 64 bits, the same single-subtraction Barrett written on one machine word.  One 1024-thread workgroup per
-// polynomial with the whole polynomial in LDS (n * 4 B <= 128 KiB): every stage is the reference's butterfly on the
-// reference's indices, so the words are the reference's for every input; twiddles come from the caller's table.
+// kernels_ntt30.hip -- the reference's 30-bit path (old/ntt_30bit.cuh): 32-bit coefficients, one prime
+// q < 2^30 per call, the caller's psi table and Barrett constant.
+//
+// Two kernel families behind the same entry points:
+//   * k_ntt30x (native): one workgroup of n/32 threads per polynomial, 32 coefficients per thread in 32 VGPRs, rounds of five
+//     in-register radix-2 stages with the polynomial exchanged through a padded LDS image between rounds (two exchanges at
+//     n = 2^15 instead of the reference's 15 synchronised stages), lazy 32-bit Harvey/Shoup butterflies (values in [0, 4q),
+//     9 VALU instructions), canonical at the end.  The Shoup companions floor(w * 2^32 / q) of the CALLER's table are
+//     recomputed by a small kernel in front of every call (k_ntt30_prepare: n exact divisions into a per-stream scratch
+//     table), so the transform always follows the table the caller passed; words equal the reference's because its
+//     single-subtraction Barrett is exact for the moduli this path is taken for (checked on the host) and both are then
+//     the exact transform.  n = 2^16 (old/ntt_30bit.cuh:271-283,323-331): one stage in memory + two independent 2^15
+//     transforms whose stage L reads table entries [2L + hL, 2L + (h+1)L) -- the same kernel with a table multiplier.
+//   * k_ntt30 / k_ntt30_stage (literal): the reference's butterflies on the reference's indices with the caller's mu
+//     (Barrett-inexact moduli, hand-made mu, table entries >= q): every stage in LDS (n <= 2^15) or one launch per stage.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "kernels.hpp"
+#include "ntt_core.cuh"
 
 namespace mi355ntt {
 
@@ -24,104 +40,487 @@ __device__ __forceinline__ u32 barrett30(u64 a, u32 q, u32 mu, int qbit)
     return (u32)a;
 }
 
+// guard words of the native path: {epoch of this call, epoch of the last call whose table had an entry >= q}
+__device__ __forceinline__ bool literal_leg_skips(const unsigned* guard) { return guard && guard[0] != guard[1]; }
+
 // all stages of CTBasedNTTInner(Single) (old/ntt_30bit.cuh:70-129, 199-227) / GSBasedINTTInner(Single) (:131-196, 229-267)
 template <int LOGN, bool FWD>
 __global__ void __launch_bounds__(1024)
-k_ntt30(u32* __restrict__ a, const u32* __restrict__ tab, u32 q, u32 mu, int qbit)
+k_ntt30(u32* __restrict__ a, const u32* __restrict__ tab, u32 q, u32 mu, int qbit, unsigned num, const unsigned* __restrict__ guard)
 {
+    if (literal_leg_skips(guard)) return;
     constexpr unsigned n = 1u << LOGN, T = n / 2 < 1024 ? n / 2 : 1024, PER = n / 2 / T;
     __shared__ u32 s[n];
-    u32* poly = a + (size_t)blockIdx.x * n;
     const unsigned t = threadIdx.x;
-    for (unsigned i = t; i < n; i += T) s[i] = poly[i];
-    __syncthreads();
     const u32 q2 = (q + 1) >> 1;
-    if constexpr (FWD) {
-        for (unsigned length = 1; length < n; length *= 2) {
-            const unsigned step = (n / length) / 2;
-            for (unsigned it = 0; it < PER; it++) {
-                const unsigned g = t + it * T;
-                const unsigned psi_step = g / step;
-                const unsigned j = psi_step * step * 2 + g % step;
-                const u32 psi = tab[length + psi_step];
-                u32 U = s[j];
-                const u32 V = barrett30((u64)s[j + step] * psi, q, mu, qbit);
-                u32 r = U + V;
-                r -= q * (r >= q);
-                s[j] = r;
-                U += q * (U < V);
-                s[j + step] = U - V;
+    for (unsigned y = blockIdx.x; y < num; y += gridDim.x) {
+        u32* poly = a + (size_t)y * n;
+        for (unsigned i = t; i < n; i += T) s[i] = poly[i];
+        __syncthreads();
+        if constexpr (FWD) {
+            for (unsigned length = 1; length < n; length *= 2) {
+                const unsigned step = (n / length) / 2;
+                for (unsigned it = 0; it < PER; it++) {
+                    const unsigned g = t + it * T;
+                    const unsigned psi_step = g / step;
+                    const unsigned j = psi_step * step * 2 + g % step;
+                    const u32 psi = tab[length + psi_step];
+                    u32 U = s[j];
+                    const u32 V = barrett30((u64)s[j + step] * psi, q, mu, qbit);
+                    u32 r = U + V;
+                    r -= q * (r >= q);
+                    s[j] = r;
+                    U += q * (U < V);
+                    s[j + step] = U - V;
+                }
+                __syncthreads();
             }
-            __syncthreads();
+        } else {
+            for (unsigned length = n / 2; length >= 1; length /= 2) {
+                const unsigned step = (n / length) / 2;
+                for (unsigned it = 0; it < PER; it++) {
+                    const unsigned g = t + it * T;
+                    const unsigned psi_step = g / step;
+                    const unsigned j = psi_step * step * 2 + g % step;
+                    const u32 psiinv = tab[length + psi_step];
+                    u32 U = s[j];
+                    const u32 V = s[j + step];
+                    u32 r = U + V;
+                    r -= q * (r >= q);
+                    s[j] = (r >> 1) + q2 * (r & 1);
+                    U += q * (U < V);
+                    const u32 d = barrett30((u64)(U - V) * psiinv, q, mu, qbit);
+                    s[j + step] = (d >> 1) + q2 * (d & 1);
+                }
+                __syncthreads();
+            }
         }
-    } else {
-        for (unsigned length = n / 2; length >= 1; length /= 2) {
-            const unsigned step = (n / length) / 2;
-            for (unsigned it = 0; it < PER; it++) {
-                const unsigned g = t + it * T;
-                const unsigned psi_step = g / step;
-                const unsigned j = psi_step * step * 2 + g % step;
-                const u32 psiinv = tab[length + psi_step];
-                u32 U = s[j];
-                const u32 V = s[j + step];
-                u32 r = U + V;
-                r -= q * (r >= q);
-                s[j] = (r >> 1) + q2 * (r & 1);
-                U += q * (U < V);
-                const u32 d = barrett30((u64)(U - V) * psiinv, q, mu, qbit);
-                s[j + step] = (d >> 1) + q2 * (d & 1);
-            }
-            __syncthreads();
+        for (unsigned i = t; i < n; i += T) poly[i] = s[i];
+        __syncthreads();
+    }
+}
+
+// one literal stage in memory (CTBasedNTTInner / GSBasedINTTInner, old/ntt_30bit.cuh:199-267): n = 2^16 and the fallback
+template <bool FWD>
+__global__ void __launch_bounds__(256)
+k_ntt30_stage(u32* __restrict__ a, const u32* __restrict__ tab, unsigned n, unsigned length, u32 q, u32 mu, int qbit, unsigned num,
+              const unsigned* __restrict__ guard)
+{
+    if (literal_leg_skips(guard)) return;
+    const unsigned half = n / 2, step = (n / length) / 2;
+    const u32 q2 = (q + 1) >> 1;
+    const size_t total = (size_t)num * half;
+    for (size_t x = (size_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (size_t)gridDim.x * 256) {
+        const unsigned y = (unsigned)(x / half), g = (unsigned)(x % half);
+        const unsigned p = g / step, j = p * step * 2 + g % step;
+        u32* poly = a + (size_t)y * n;
+        const u32 w = tab[length + p];
+        u32 U = poly[j];
+        if constexpr (FWD) {
+            const u32 V = barrett30((u64)poly[j + step] * w, q, mu, qbit);
+            u32 r = U + V;
+            r -= q * (r >= q);
+            poly[j] = r;
+            U += q * (U < V);
+            poly[j + step] = U - V;
+        } else {
+            const u32 V = poly[j + step];
+            u32 r = U + V;
+            r -= q * (r >= q);
+            poly[j] = (r >> 1) + q2 * (r & 1);
+            U += q * (U < V);
+            const u32 d = barrett30((u64)(U - V) * w, q, mu, qbit);
+            poly[j + step] = (d >> 1) + q2 * (d & 1);
         }
     }
-    for (unsigned i = t; i < n; i += T) poly[i] = s[i];
 }
 
 // barrett_30bit, old/ntt_30bit.cuh:10-35
 __global__ void __launch_bounds__(256)
 k_barrett30(u32* __restrict__ a, const u32* __restrict__ b, size_t count, u32 q, u32 mu, int qbit)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    u64 rc = (u64)a[i] * b[i];
-    u64 rx = rc >> (qbit - 2);
-    rx *= mu;
-    rx >>= qbit + 2;
-    rx *= q;
-    rc -= rx;
-    a[i] = rc < q ? (u32)rc : (u32)(rc - q);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        u64 rc = (u64)a[i] * b[i];
+        u64 rx = rc >> (qbit - 2);
+        rx *= mu;
+        rx >>= qbit + 2;
+        rx *= q;
+        rc -= rx;
+        a[i] = rc < q ? (u32)rc : (u32)(rc - q);
+    }
+}
+
+// ================================================================================================ native path
+// scratch of one (device, stream): header + the caller's table with Shoup companions
+struct Scratch30 {
+    unsigned guard[2];       // {epoch, epoch of the last table with an entry >= q}
+    u32 ninv, ninv_p;        // m^-1 mod q for the transform size m the kernel runs (n, or n/2 for the split) + companion
+    u32 w1n[2], w1n_p[2];    // psiinv-table entry of the last GS stage (index A: 1, or 2 + h for half h) times ninv + companions
+    unsigned pad[8];
+    uint2 tw[65536];         // {w, floor(w * 2^32 / q)}
+};
+
+__device__ __forceinline__ u32 shoup32_companion(u32 w, u32 q) { return (u32)(((u64)w << 32) / q); }
+
+__global__ void __launch_bounds__(256)
+k_ntt30_prepare(const u32* __restrict__ tab, unsigned n, u32 q, u32 ninv, unsigned split, Scratch30* __restrict__ sc, unsigned epoch)
+{
+    bool bad = false;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const u32 w = tab[i];
+        if (w >= q && i != 0) bad = true;                  // (entry 0 is never read)
+        sc->tw[i] = make_uint2(w, shoup32_companion(w < q ? w : 0, q));
+    }
+    if (bad) atomicMax(&sc->guard[1], epoch);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->guard[0] = epoch;
+        sc->ninv = ninv;
+        sc->ninv_p = shoup32_companion(ninv, q);
+        for (unsigned h = 0; h < 2; h++) {
+            const u32 w1 = tab[split ? 2 + h : 1] % q;
+            const u32 v = (u32)(((u64)w1 * ninv) % q);
+            sc->w1n[h] = v;
+            sc->w1n_p[h] = shoup32_companion(v, q);
+        }
+    }
+}
+
+__device__ __forceinline__ u32 min_u32(u32 a, u32 b) { return a < b ? a : b; }
+// y * w mod q in [0, 2q) for ANY 32-bit y (w < q, wp = floor(w 2^32 / q))
+__device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return y * w - __umulhi(y, wp) * q; }
+
+// LDS image of the native kernel: element i at word i + (i >> 5) (one pad word per 32: every access pattern of the three
+// layouts is conflict-free or 2-way).  Thread part and register part of an index occupy disjoint bit fields, so the slot
+// splits into a per-thread base and a compile-time offset per register.
+constexpr unsigned pad32(unsigned i) { return i + (i >> 5); }
+
+template <int BO, int BN>
+__device__ __forceinline__ void exchange32(u32 (&v)[32], u32* img, unsigned t)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    // DS instructions carry a 16-bit byte offset: the image (up to 132 KiB) is addressed through three bases 64 KiB apart,
+    // pinned so that the compiler does not materialise one address per register
+    constexpr unsigned SEG = 16384;                     // words per 64 KiB
+    unsigned wb0 = pad32(elem_index<BO>(t, 0)), rb0 = pad32(elem_index<BN>(t, 0));
+    asm volatile("" : "+v"(wb0), "+v"(rb0));
+    unsigned wb1 = wb0 + SEG, wb2 = wb0 + 2 * SEG, rb1 = rb0 + SEG, rb2 = rb0 + 2 * SEG;
+    asm volatile("" : "+v"(wb1), "+v"(wb2), "+v"(rb1), "+v"(rb2));
+    u32* const wb[3] = {img + wb0, img + wb1, img + wb2};
+    const u32* const rb[3] = {img + rb0, img + rb1, img + rb2};
+    static_for<32>([&](auto rc) {
+        constexpr unsigned off = pad32((unsigned)decltype(rc)::value << BO);
+        wb[off / SEG][off % SEG] = v[decltype(rc)::value];
+    });
+    __syncthreads();
+    static_for<32>([&](auto rc) {
+        constexpr unsigned off = pad32((unsigned)decltype(rc)::value << BN);
+        v[decltype(rc)::value] = rb[off / SEG][off % SEG];
+    });
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Twiddles of butterfly group G of a round: 8 butterflies per group, two groups per stage, the loads run one group ahead
+// (a ring of 2 x 8 pairs = 32 VGPRs); scheduling fences around each group keep the compiler from hoisting a whole round's
+// loads (which cost the first version 144 VGPRs and spills).
+constexpr int GROUP32 = 8;
+template <int LOGN, int B, int JA, bool FWD, int G>
+__device__ __forceinline__ void load_tw32(uint2 (&W)[GROUP32], const uint2* __restrict__ tw, BufRsrc twr, unsigned tmul, unsigned thi)
+{
+    constexpr int j = FWD ? JA - G / 2 : JA + G / 2;
+    constexpr unsigned len = 1u << (LOGN - 1 - (B + j));
+    if constexpr (B == Geo<LOGN>::B0) {                  // first / last round: the group index does not depend on the thread -> scalar loads
+        static_for<GROUP32>([&](auto kc) {
+            constexpr int r0 = low_reg(j, (G % 2) * GROUP32 + decltype(kc)::value);
+            W[decltype(kc)::value] = tw[len * tmul + ((unsigned)r0 >> (j + 1))];
+        });
+    } else {                                             // one 32-bit lane offset, the rest in the scalar offset / immediate
+        const unsigned voff = (thi << (4 - j)) * 8u;
+        const unsigned soff = len * tmul * 8u;
+        static_for<GROUP32>([&](auto kc) {
+            constexpr int r0 = low_reg(j, (G % 2) * GROUP32 + decltype(kc)::value);
+            const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(twr, voff + ((unsigned)r0 >> (j + 1)) * 8u, soff, 0);
+            W[decltype(kc)::value] = make_uint2(x.x, x.y);
+        });
+    }
+}
+
+// CT stages on register bits JHI..0 of the layout with register field at bit B.  Values in [0, 4q): the first operand is
+// brought below 2q (one v_sub + v_min), the Shoup product lies in [0, 2q) for any 32-bit multiplicand.
+// tmul: table multiplier (1; 2 + h for half h of a split transform: stage L then reads entries [L tmul, L tmul + L)).
+template <int LOGN, int B, int JHI>
+__device__ __forceinline__ void ct_round32(u32 (&v)[32], const uint2* __restrict__ tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q)
+{
+    const u32 twoq = 2 * q;
+    const unsigned thi = t >> B;
+    constexpr int NG = (JHI + 1) * 2;
+    uint2 W[2][GROUP32];
+    load_tw32<LOGN, B, JHI, true, 0>(W[0], tw, twr, tmul, thi);
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int j = JHI - g / 2;
+        if constexpr (g + 1 < NG) load_tw32<LOGN, B, JHI, true, g + 1>(W[(g + 1) % 2], tw, twr, tmul, thi);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<GROUP32>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int r0 = low_reg(j, (g % 2) * GROUP32 + k), r1 = r0 | (1 << j);
+            const uint2 w = W[g % 2][k];
+            const u32 X = min_u32(v[r0], v[r0] - twoq);
+            const u32 T = shoup32(v[r1], w.x, w.y, q);
+            v[r0] = X + T;
+            v[r1] = X + twoq - T;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// GS stages on register bits JLO..4.  Values in [0, 2q) between stages; the stage on index bit LOGN - 1 (length 1) carries
+// m^-1: both outputs are Shoup products (the reference halves in every stage instead, old/ntt_30bit.cuh:131-196).
+template <int LOGN, int B, int JLO>
+__device__ __forceinline__ void gs_round32(u32 (&v)[32], const uint2* __restrict__ tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, const Scratch30* sc_, unsigned h)
+{
+    const u32 twoq = 2 * q;
+    const unsigned thi = t >> B;
+    constexpr int NG = (5 - JLO) * 2;
+    uint2 W[2][GROUP32];
+    load_tw32<LOGN, B, JLO, false, 0>(W[0], tw, twr, tmul, thi);
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int j = JLO + g / 2;
+        constexpr int beta = B + j;
+        constexpr bool last = (beta == LOGN - 1);
+        if constexpr (g + 1 < NG) load_tw32<LOGN, B, JLO, false, g + 1>(W[(g + 1) % 2], tw, twr, tmul, thi);
+        __builtin_amdgcn_sched_barrier(0);
+        u32 ninv = 0, ninv_p = 0, w1n = 0, w1n_p = 0;
+        if constexpr (last) {
+            ninv = sc_->ninv; ninv_p = sc_->ninv_p; w1n = sc_->w1n[h]; w1n_p = sc_->w1n_p[h];
+        }
+        static_for<GROUP32>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int r0 = low_reg(j, (g % 2) * GROUP32 + k), r1 = r0 | (1 << j);
+            const u32 X = v[r0], Y = v[r1];
+            u32 S = X + Y;
+            S = min_u32(S, S - twoq);
+            const u32 D = X + twoq - Y;
+            if constexpr (last) {
+                v[r0] = shoup32(S, ninv, ninv_p, q);
+                v[r1] = shoup32(D, w1n, w1n_p, q);
+            } else {
+                const uint2 w = W[g % 2][k];
+                v[r0] = S;
+                v[r1] = shoup32(D, w.x, w.y, q);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+template <int LOGN, int RHO>
+__device__ __forceinline__ void fwd_rounds32(u32 (&v)[32], const uint2* tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, u32* img)
+{
+    using G = Geo<LOGN>;
+    if constexpr (RHO < G::NR) {
+        constexpr int TOP = LOGN - 1 - 5 * RHO;
+        constexpr int B = TOP - 4 > 0 ? TOP - 4 : 0;
+        if constexpr (RHO > 0) {
+            constexpr int TOPP = LOGN - 1 - 5 * (RHO - 1);
+            constexpr int BP = TOPP - 4 > 0 ? TOPP - 4 : 0;
+            exchange32<BP, B>(v, img, t);
+        }
+        ct_round32<LOGN, B, TOP - B>(v, tw, twr, tmul, t, q);
+        fwd_rounds32<LOGN, RHO + 1>(v, tw, twr, tmul, t, q, img);
+    }
+}
+
+template <int LOGN, int RHO>
+__device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, u32* img, const Scratch30* sc, unsigned h)
+{
+    using G = Geo<LOGN>;
+    if constexpr (RHO < G::NR) {
+        constexpr int LOW = 5 * RHO;
+        constexpr int B = LOW < G::B0 ? LOW : G::B0;
+        if constexpr (RHO > 0) {
+            constexpr int LOWP = 5 * (RHO - 1);
+            constexpr int BP = LOWP < G::B0 ? LOWP : G::B0;
+            exchange32<BP, B>(v, img, t);
+        }
+        gs_round32<LOGN, B, LOW - B>(v, tw, twr, tmul, t, q, sc, h);
+        inv_rounds32<LOGN, RHO + 1>(v, tw, twr, tmul, t, q, img, sc, h);
+    }
+}
+
+// One workgroup of 2^LOGN / 32 threads per polynomial of 2^LOGN words, persistent over the batch.  split: the polynomials
+// are the halves of 2^(LOGN+1)-word polynomials whose first (forward) / last (inverse) stage runs as a stage launch.
+template <int LOGN, bool FWD>
+__global__ void __launch_bounds__(Geo<LOGN>::T)
+k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned num, unsigned split)
+{
+    if (sc->guard[0] == sc->guard[1]) return;            // a table entry >= q: the literal leg transforms the data
+    using G = Geo<LOGN>;
+    constexpr unsigned n = G::N;
+    __shared__ u32 img[pad32(n)];
+    const unsigned t = threadIdx.x;
+    const uint2* tw = sc->tw;
+    const BufRsrc twr = make_rsrc(tw, 65536u * 8u);
+    // the next polynomial's coefficients are loaded into a second register set while the current one is transformed (one
+    // workgroup per CU at n = 2^15: nothing else would cover the memory latency)
+    u32 v[32], nx[32];
+    auto issue_loads = [&](u32 (&dst)[32], unsigned y) {
+        const BufRsrc rs = make_rsrc(a + (size_t)y * n, n * 4u);
+        static_for<32>([&](auto rc) { dst[decltype(rc)::value] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
+    };
+    if (blockIdx.x < num) issue_loads(v, blockIdx.x);
+    for (unsigned y = blockIdx.x; y < num; y += gridDim.x) {
+        const BufRsrc prs = make_rsrc(a + (size_t)y * n, n * 4u);
+        const unsigned h = split ? (y & 1u) : 0u, tmul = split ? 2u + h : 1u;
+        const bool more = y + gridDim.x < num;
+        if (more) issue_loads(nx, y + gridDim.x);
+        if constexpr (FWD) {
+            fwd_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img);
+            static_for<32>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                u32 x = min_u32(v[r], v[r] - 2 * q);
+                v[r] = min_u32(x, x - q);
+            });
+            exchange32<0, G::B0>(v, img, t);             // layout 0 (32 consecutive words per thread) -> coalesced layout
+        } else {
+            exchange32<G::B0, 0>(v, img, t);
+            inv_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img, sc, h);
+            static_for<32>([&](auto rc) { v[decltype(rc)::value] = min_u32(v[decltype(rc)::value], v[decltype(rc)::value] - q); });
+        }
+        static_for<32>([&](auto rc) { __builtin_amdgcn_raw_buffer_store_b32(v[decltype(rc)::value], prs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
+        if (more) static_for<32>([&](auto rc) { v[decltype(rc)::value] = nx[decltype(rc)::value]; });
+    }
+}
+
+// ---- scratch per (device, stream) -----------------------------------------------------------------------------------
+std::mutex g_scratch_mutex;
+std::map<std::pair<int, hipStream_t>, Scratch30*> g_scratch;
+unsigned g_epoch = 0;
+
+Scratch30* scratch_for(hipStream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    auto key = std::make_pair(dev, s);
+    auto it = g_scratch.find(key);
+    if (it != g_scratch.end()) return it->second;
+    Scratch30* p = nullptr;
+    if (hipMalloc((void**)&p, sizeof(Scratch30)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 64) != hipSuccess) {
+        (void)hipFree(p);
+        return nullptr;
+    }
+    g_scratch[key] = p;
+    return p;
+}
+
+unsigned next_epoch()
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (++g_epoch == 0) g_epoch = 1;
+    return g_epoch;
+}
+
+template <int LOGN, bool FWD>
+void launch_native(u32* d_a, const Scratch30* sc, u32 q, unsigned num, unsigned split, hipStream_t s)
+{
+    const unsigned lds = pad32(1u << LOGN) * 4u, per_cu_lds = 163840u / lds, per_cu_waves = 32u / (Geo<LOGN>::T / 64u);
+    unsigned per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned cap = 256u * per_cu;
+    k_ntt30x<LOGN, FWD><<<num < cap ? num : cap, Geo<LOGN>::T, 0, s>>>(d_a, sc, q, num, split);
 }
 
 template <bool FWD>
-hipError_t launch30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s)
+void launch_literal_lds(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s,
+                        const unsigned* guard)
 {
-    dim3 g(num);
+    const unsigned g = num < 512u ? num : 512u;
     switch (n) {
-    case 2048: k_ntt30<11, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits); break;
-    case 4096: k_ntt30<12, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits); break;
-    case 8192: k_ntt30<13, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits); break;
-    case 16384: k_ntt30<14, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits); break;
-    case 32768: k_ntt30<15, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits); break;
+    case 2048: k_ntt30<11, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
+    case 4096: k_ntt30<12, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
+    case 8192: k_ntt30<13, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
+    case 16384: k_ntt30<14, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
+    default: k_ntt30<15, FWD><<<g < 256u ? g : 256u, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
+    }
+}
+
+template <bool FWD>
+void launch_stage(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned length, unsigned num, unsigned q, unsigned mu, int bits,
+                  hipStream_t s, const unsigned* guard)
+{
+    const size_t total = (size_t)num * (n / 2);
+    const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    k_ntt30_stage<FWD><<<g, 256, 0, s>>>(d_a, d_tab, n, length, q, mu, bits, num, guard);
+}
+
+// the literal transform (the reference's arithmetic with the caller's mu); guard: run only as the fallback leg
+template <bool FWD>
+void launch_literal(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s,
+                    const unsigned* guard, bool skip_split_stage)
+{
+    if (n <= 32768) {
+        launch_literal_lds<FWD>(d_a, n, d_tab, num, q, mu, bits, s, guard);
+        return;
+    }
+    if (FWD) {
+        for (unsigned length = skip_split_stage ? 2 : 1; length < n; length *= 2) launch_stage<true>(d_a, n, d_tab, length, num, q, mu, bits, s, guard);
+    } else {
+        for (unsigned length = n / 2; length >= (skip_split_stage ? 2u : 1u); length /= 2)
+            launch_stage<false>(d_a, n, d_tab, length, num, q, mu, bits, s, guard);
+    }
+}
+
+template <bool FWD>
+hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, unsigned ninv_native,
+                 hipStream_t s)
+{
+    if (ninv_native == 0) {                               // literal kernels only (hand-made mu / Barrett-inexact modulus)
+        launch_literal<FWD>(d_a, n, d_tab, num, q, mu, bits, s, nullptr, false);
+        return hipGetLastError();
+    }
+    Scratch30* sc = scratch_for(s);
+    if (!sc) return hipErrorOutOfMemory;
+    const unsigned epoch = next_epoch();
+    const unsigned split = n == 65536 ? 1u : 0u;
+    k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_native, split, sc, epoch);
+    if (split && FWD) launch_stage<true>(d_a, n, d_tab, 1, num, q, mu, bits, s, nullptr);       // stage 1 couples the two halves
+    const unsigned m = split ? n / 2 : n, cnt = split ? 2 * num : num;
+    switch (m) {
+    case 2048: launch_native<11, FWD>(d_a, sc, q, cnt, split, s); break;
+    case 4096: launch_native<12, FWD>(d_a, sc, q, cnt, split, s); break;
+    case 8192: launch_native<13, FWD>(d_a, sc, q, cnt, split, s); break;
+    case 16384: launch_native<14, FWD>(d_a, sc, q, cnt, split, s); break;
+    case 32768: launch_native<15, FWD>(d_a, sc, q, cnt, split, s); break;
     default: return hipErrorInvalidValue;
     }
+    launch_literal<FWD>(d_a, n, d_tab, num, q, mu, bits, s, sc->guard, split != 0);             // fallback leg (a table entry >= q)
+    if (split && !FWD) launch_stage<false>(d_a, n, d_tab, 1, num, q, mu, bits, s, nullptr);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t ntt30_forward(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s)
+// ninv_native: m^-1 mod q for the size m the native kernel transforms (n, or n / 2 at n = 2^16) when the call may take the
+// native kernels (mu and bits are the canonical ones and the single-subtraction Barrett is exact for q), else 0.
+hipError_t ntt30_forward(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, unsigned ninv_native,
+                         hipStream_t s)
 {
-    return launch30<true>(d_a, n, d_tab, num, q, mu, bits, s);
+    return run30<true>(d_a, n, d_tab, num, q, mu, bits, ninv_native, s);
 }
 
-hipError_t ntt30_inverse(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s)
+hipError_t ntt30_inverse(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, unsigned ninv_native,
+                         hipStream_t s)
 {
-    return launch30<false>(d_a, n, d_tab, num, q, mu, bits, s);
+    return run30<false>(d_a, n, d_tab, num, q, mu, bits, ninv_native, s);
 }
 
 hipError_t ntt30_barrett(unsigned* d_a, const unsigned* d_b, size_t count, unsigned q, unsigned mu, int bits, hipStream_t s)
 {
-    k_barrett30<<<dim3((unsigned)((count + 255) / 256)), 256, 0, s>>>(d_a, d_b, count, q, mu, bits);
+    const size_t blocks = (count + 255) / 256;
+    k_barrett30<<<(unsigned)(blocks < 65536 ? blocks : 65536), 256, 0, s>>>(d_a, d_b, count, q, mu, bits);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@ PARAMS30 = {
     8192: (8716289, 1089, 8196033, 8715225, 24),
     16384: (13664257, 273, 8959348, 13663423, 24),
     32768: (19070977, 377, 16642842, 19070395, 25),
+    65536: (13631489, 13, 12582913, 13631281, 24),       # BFV_Scheme/parameter.h:129-136 (old/ntt_30bit.cuh dispatches N = 65536, :271-283,323-331)
 }
 
 
@@ -74,6 +75,43 @@ def test_gpu_30bit_path_matches_oracle(native, oracle, gpu, n):
     assert np.array_equal(host32(d_a), oracle.inverse30(AB, prm))
     native.inverse30(d_b, n, q, prm.mu, bits, d_psiinv, num)
     assert np.array_equal(host32(d_b), b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 32768, 65536])
+def test_gpu_30bit_literal_fallbacks_match_oracle(native, oracle, gpu, n):
+    """The native 30-bit kernels are taken only for the canonical mu and a table of residues; a hand-made mu runs the
+    literal kernels from the host side, a table entry >= q is caught on the device (the companion pass in front of every
+    call) and sends the call to the literal leg: both must give the words of the oracle's literal arithmetic."""
+    import torch
+    q, psi, _, _, bits = PARAMS30[n]
+    prm = oracle.Params30(n, q, psi)
+    num = 3
+    rng = np.random.default_rng(11 * n)
+    a = rng.integers(0, q, size=(num, n), dtype=np.uint32)
+    dev32 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(gpu)
+    host32 = lambda t: t.cpu().numpy().view(np.uint32)
+    d_psi, d_psiinv = dev32(prm.psi_tab), dev32(prm.psiinv_tab)
+    # (1) mu one too small
+    prm2 = oracle.Params30(n, q, psi)
+    prm2.mu -= 1
+    d_a = dev32(a)
+    native.forward30(d_a, n, q, prm2.mu, bits, d_psi, num)
+    A2 = oracle.forward30(a, prm2)
+    assert np.array_equal(host32(d_a), A2)
+    native.inverse30(d_a, n, q, prm2.mu, bits, d_psiinv, num)
+    assert np.array_equal(host32(d_a), oracle.inverse30(A2, prm2))
+    # (2) a table entry q + w instead of w (same residue, not canonical): the literal arithmetic on exactly that table
+    prm3 = oracle.Params30(n, q, psi)
+    prm3.psi_tab = prm3.psi_tab.copy()
+    prm3.psi_tab[n // 2 + 3] += q
+    d_a = dev32(a)
+    native.forward30(d_a, n, q, prm3.mu, bits, dev32(prm3.psi_tab), num)
+    assert np.array_equal(host32(d_a), oracle.forward30(a, prm3))
+    # (3) and the clean table right afterwards on the same stream: the native kernels again
+    d_a = dev32(a)
+    native.forward30(d_a, n, q, prm.mu, bits, d_psi, num)
+    assert np.array_equal(host32(d_a), oracle.forward30(a, prm))
 
 
 def test_30bit_entry_points_reject_bad_arguments(native):
