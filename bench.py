@@ -192,6 +192,32 @@ def bfv_round_trip(torch, ntt, n, dev, with_cpu, qs, psis, label):
     assert torch.equal(cd.reshape(-1)[off: off + n], m), "BFV round trip failed"
     out = {"workload": "n=%d, %s, t=%d, 61-bit gamma; drivers after the samplers, one ciphertext" % (n, label, BFV_T),
            "keygen_us": keygen_us, "encrypt_us": encrypt_us, "decrypt_us": decrypt_us, "round_trip_ok": True}
+
+    # the batched drivers: 64 ciphertexts per call, layout [2][64][R][n]; same public/secret key, fresh u / e / m each
+    B = 64
+    ub = torch.stack([ternary() for _ in range(B)])
+    cb0 = torch.stack([ub, ub]).contiguous()
+    eb = torch.stack([torch.stack([err() for _ in range(B)]) for _ in range(2)]).contiguous()
+    mb = torch.randint(0, BFV_T, (B, n), dtype=torch.int64, device=dev, generator=g)
+
+    def encrypt_b(a):
+        if a is None:
+            return (cb0.clone(),)
+        ctx.encrypt_batch(a[0], pk, eb, mb, B)
+
+    enc_b_us, (cb,) = timed(encrypt_b, reps=10)
+    cb_keep = cb.clone()
+
+    def decrypt_b(a):
+        if a is None:
+            return (cb_keep.clone(),)
+        ctx.decrypt_batch(a[0], sk, B)
+
+    dec_b_us, (cbd,) = timed(decrypt_b, reps=10)
+    assert torch.equal(cbd.reshape(2, B, R, n)[0, :, R - 2], mb), "batched BFV round trip failed"
+    out["batch64"] = {"layout": "[2][64][R][n]", "encrypt_us_per_call": enc_b_us, "decrypt_us_per_call": dec_b_us,
+                      "encrypt_ciphertexts_per_s": B / (enc_b_us * 1e-6), "decrypt_ciphertexts_per_s": B / (dec_b_us * 1e-6),
+                      "encrypt_us_per_ciphertext": enc_b_us / B, "decrypt_us_per_ciphertext": dec_b_us / B, "round_trip_ok": True}
     if with_cpu:
         import numpy as np
         import oracle_py as oracle

@@ -137,6 +137,13 @@ int mi355ntt_pointwise_mul_scalar(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, mi
 int mi355ntt_polymul_batch(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, const mi355ntt_u64* d_bhat,
                            unsigned num, unsigned division, mi355ntt_stream stream);
 
+/* The same with second operands shared by the batch: `division` of them per key group of `group` consecutive
+ * polynomials (group a multiple of division; 0 = the whole batch is one group): polynomial y multiplies with
+ * d_bhat[(y / group) division + y % division].  The batched BFV drivers multiply every ciphertext with the same key
+ * this way (encryption: two groups, the two components of the public key). */
+int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, const mi355ntt_u64* d_bhat,
+                                  unsigned num, unsigned division, unsigned group, mi355ntt_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Raw-parameter entry points: signature-compatible with the reference (the caller supplies q, mu, bit_length and
  * reference-format device tables on every call, ntt_60bit.cuh:314,350,608,652 + the __constant__ moduli of :8-10).
@@ -240,6 +247,17 @@ int mi355ntt_bfv_encrypt(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355
 /* decryption_rns (bfv_decryption.cuh:76-138).  d_secret_key: first num_primes - 1 polynomials of the NTT-domain key.
  * d_c is overwritten exactly as the reference overwrites it; the plaintext is at d_c + n * (num_primes - 2). */
 int mi355ntt_bfv_decrypt(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_secret_key, mi355ntt_stream stream);
+
+/* Batched drivers: `count` ciphertexts per call in the layout [2][count][num_primes][n] (all first components, then all
+ * second components; d_e the same, d_m [count][n]); each ciphertext gets exactly the words mi355ntt_bfv_encrypt /
+ * _decrypt leave for it (except that decryption also overwrites the second component's slot of the dropped last
+ * prime, which the single driver leaves alone and nothing reads).  The secret key must hold all num_primes polynomials (keygen's output); plaintext of
+ * ciphertext z: d_c + (z num_primes + num_primes - 2) n.  One fused product per component for the whole batch and one
+ * launch per element-wise step, instead of the per-ciphertext launch sequence (which is bound by launch overhead). */
+int mi355ntt_bfv_encrypt_batch(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
+                               const mi355ntt_u64* d_m, unsigned count, mi355ntt_stream stream);
+int mi355ntt_bfv_decrypt_batch(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_secret_key, unsigned count,
+                               mi355ntt_stream stream);
 
 /* ---- samplers and the complete drivers --------------------------------------------------
  * generate_random / generate_random_default (distributions.cuh:192-276): Salsa20/20 keystream, floor(nbytes / 64)

@@ -55,11 +55,11 @@ hipError_t bfv_sample_encrypt(const BfvParams& p, const BfvDevice& d, const unsi
 hipError_t bfv_add_negate(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* e, hipStream_t s);
 // poly_add_xq + divide_and_round_q_last_inplace_add_x2 + divide_and_round_q_last_inplace_loop_xq + weird_m_stuff
 // (bfv_encryption.cuh:110-208) on c [2][R][n], e [2][R][n], m [n]: one pass, same words as the four launches
-hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s);
+hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s, unsigned count = 1);
 // poly_add_xq_d + poly_mul_int_xq_prodtgamma + poly_mul_int_xq_invpq (bfv_decryption.cuh:13-57) on c [2][R][n]
-hipError_t bfv_decrypt_scale(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s);
+hipError_t bfv_decrypt_scale(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count = 1);
 // fast_convert_array_kernel_t/_gamma, mod_t, barrett_int (gamma), dec_round_kernel (poly_arithmetic.cuh:128-142,
 // 221-268): leaves the same words as the reference in c[0, n), c[n, 2n) and the plaintext at c + n (r - 1)
-hipError_t bfv_decrypt_round(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s);
+hipError_t bfv_decrypt_round(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count = 1);
 
 }  // namespace mi355ntt

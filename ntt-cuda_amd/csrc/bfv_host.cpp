@@ -212,6 +212,36 @@ int mi355ntt_bfv_decrypt(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355nt
     return MI355NTT_OK;
 }
 
+/* ---- batched drivers: `count` ciphertexts per call, laid out [2][count][num_primes][n] (component-major, so that each
+ * component of the whole batch is one contiguous run of polynomials for the fused product) ---- */
+int mi355ntt_bfv_encrypt_batch(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
+                               const mi355ntt_u64* d_m, unsigned count, mi355ntt_stream stream)
+{
+    if (!b || !d_c || !d_public_key || !d_e || !d_m) return MI355NTT_EINVAL;
+    if (count == 0) return MI355NTT_OK;
+    const unsigned R = b->p.R;
+    BFV_ON_DEVICE(b);
+    /* :268-271 for the whole batch in one launch: the first count R polynomials with pk0, the rest with pk1 */
+    BFV_RC(mi355ntt_polymul_batch_shared(b->ntt, d_c, d_public_key, 2 * count * R, R, count * R, stream));
+    BFV_HIP(bfv_encrypt_tail(b->p, b->d, d_c, d_e, d_m, (hipStream_t)stream, count));                            /* :278-289 */
+    return MI355NTT_OK;
+}
+
+int mi355ntt_bfv_decrypt_batch(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355ntt_u64* d_secret_key, unsigned count,
+                               mi355ntt_stream stream)
+{
+    if (!b || !d_c || !d_secret_key) return MI355NTT_EINVAL;
+    if (count == 0) return MI355NTT_OK;
+    const unsigned R = b->p.R;
+    const size_t half = (size_t)count * R * b->p.n;
+    BFV_ON_DEVICE(b);
+    /* bfv_decryption.cuh:98-101 on the c1 run of the batch; the slot of the dropped last prime is carried along unused */
+    BFV_RC(mi355ntt_polymul_batch_shared(b->ntt, d_c + half, d_secret_key, count * R, R, 0, stream));
+    BFV_HIP(bfv_decrypt_scale(b->p, b->d, d_c, (hipStream_t)stream, count));                                     /* :103-121 */
+    BFV_HIP(bfv_decrypt_round(b->p, b->d, d_c, (hipStream_t)stream, count));                                     /* :126-137 */
+    return MI355NTT_OK;
+}
+
 /* ---------------- samplers and the complete drivers ---------------- */
 
 static BfvSalsaKey salsa_key(const unsigned char* key32)

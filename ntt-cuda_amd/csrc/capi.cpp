@@ -372,6 +372,26 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355
     return MI355NTT_OK;
 }
 
+int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355ntt_u64* d_bhat, unsigned num,
+                                  unsigned division, unsigned group, mi355ntt_stream s)
+{
+    int rc = check_batch(c, d_a, num, division);
+    if (rc) return rc;
+    if (!d_bhat || (group && group % division) || group >= (1u << 23)) return MI355NTT_EINVAL;
+    if (num == 0) return MI355NTT_OK;
+    ON_CTX_DEVICE(c);
+    if (!c->literal && !c->split16) {
+        const hipError_t e = fast_polymul_batch(c->fast, d_a, d_bhat, num, division, (hipStream_t)s, true, group);
+        if (e == hipSuccess) return MI355NTT_OK;
+        if (e != hipErrorNotSupported) HIP_TRY(e);
+    }
+    // the three steps (literal kernels, n = 65536, and the sizes without a fused kernel)
+    HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
+    HIP_TRY(compat_pointwise(d_a, d_a, d_bhat, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s, true, group));
+    HIP_TRY(run_inverse(c, d_a, num, division, 0, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+
 /* ---------------- raw-parameter entry points ---------------- */
 static int fill_modset(ModSet* m, unsigned division, const mi355ntt_u64* q, const mi355ntt_u64* mu, const unsigned* bits)
 {

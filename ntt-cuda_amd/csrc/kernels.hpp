@@ -21,6 +21,12 @@ struct ModSet {
 // kGuardBit set in prime_base return at once when g[0] == g[1] (this call's table is not the cached one), the literal
 // kernels launched with a guard pointer return at once when g[0] != g[1] -- exactly one of the two transforms the data.
 constexpr unsigned kGuardBit = 0x80000000u;
+// fused products: OR-ed into `division`, the second operand holds `division` polynomials shared by the whole batch
+// (polynomial y multiplies with bhat[y % division]) -- the batched BFV drivers multiply every ciphertext with the same key
+constexpr unsigned kSharedB = 0x80000000u;
+// with kSharedB: bits 8..30 of the division word = polynomials per key group (0: one group); polynomial y then multiplies
+// with bhat[(y / group) * division + y % division] -- the two components of a batch of ciphertexts in one launch
+constexpr unsigned kSharedGroupShift = 8, kDivisionMask = 0xffu;
 
 // ---- literal stage-per-launch kernels (kernels_compat.hip) ----
 hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,
@@ -33,7 +39,7 @@ hipError_t compat_ct_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned len
 hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsigned num, unsigned division, const ModSet& m,
                            hipStream_t s);
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
-                            const ModSet& m, hipStream_t s);
+                            const ModSet& m, hipStream_t s, bool shared_b = false, unsigned group = 0);
 hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s);
 // *d_flag |= 1 when two sets of `count` reference-format tables differ in an entry the transforms read (index != 0)
 hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_flag, hipStream_t s);
@@ -66,7 +72,8 @@ hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsig
 hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);
 hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u64* d_b, unsigned num, unsigned division,
                           hipStream_t s);
-hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s);
+hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
+                              bool shared_b = false, unsigned group = 0);
 
 // ---- the reference's 30-bit path (kernels_ntt30.hip): 32-bit words, single prime, `num` polynomials of n words ----
 // ninv_native: m^-1 mod q (m = n, or n / 2 at n = 2^16) when the call may run the native kernels, 0 = literal kernels only

@@ -31,13 +31,15 @@ k_add_negate(u64* __restrict__ a, const u64* __restrict__ b, unsigned n, const B
 // +half on the last one (:110-124), subtract-and-scale on the others (:126-171), message term on c0 (:186-208)
 __global__ void __launch_bounds__(kBlock)
 k_encrypt_tail(u64* __restrict__ c, const u64* __restrict__ e, const u64* __restrict__ m, unsigned n, unsigned R, u64 t,
-               const BfvPrime* __restrict__ primes)
+               const BfvPrime* __restrict__ primes, size_t half_stride)
 {
+    // blockIdx.z: ciphertext of a batch laid out [2][count][R][n] (half_stride = count R n; one ciphertext: R n, gridDim.z = 1)
     const unsigned h = blockIdx.y;
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const unsigned r = R - 1;
-    u64* ch = c + (size_t)h * R * n;
-    const u64* eh = e + (size_t)h * R * n;
+    u64* ch = c + (size_t)blockIdx.z * R * n + h * half_stride;
+    const u64* eh = e + (size_t)blockIdx.z * R * n + h * half_stride;
+    m += (size_t)blockIdx.z * n;
     const u64 q_last = primes[r].q, half_last = q_last >> 1;
     u64 last = ch[(size_t)r * n + i] + eh[(size_t)r * n + i];
     if (last > q_last) last -= q_last;                         // poly_add_xq
@@ -66,12 +68,13 @@ k_encrypt_tail(u64* __restrict__ c, const u64* __restrict__ e, const u64* __rest
 
 // c1[i] = ((c1[i] + c0[i], `>`) * prod_t_gamma) * inv_punctured_q, bfv_decryption.cuh:13-57
 __global__ void __launch_bounds__(kBlock)
-k_decrypt_scale(u64* __restrict__ c, unsigned n, unsigned R, const BfvPrime* __restrict__ primes)
+k_decrypt_scale(u64* __restrict__ c, unsigned n, unsigned R, const BfvPrime* __restrict__ primes, size_t half_stride)
 {
     const unsigned y = blockIdx.y;
     const BfvPrime p = primes[y];
     const size_t i = (size_t)y * n + blockIdx.x * kBlock + threadIdx.x;
-    u64* c1 = c + (size_t)R * n;
+    c += (size_t)blockIdx.z * R * n;
+    u64* c1 = c + half_stride;
     u64 ra = c1[i] + c[i];
     if (ra > p.q) ra -= p.q;
     ra = barrett_mul(ra, p.prod_t_gamma_mod_q, p.q, p.mu, p.k);
@@ -82,11 +85,12 @@ k_decrypt_scale(u64* __restrict__ c, unsigned n, unsigned R, const BfvPrime* __r
 // poly_arithmetic.cuh:221-268, :128-142, barrett_int (:100-126) per column k
 __global__ void __launch_bounds__(kBlock)
 k_decrypt_round(u64* __restrict__ c, unsigned n, unsigned R, u64 t, u64 gamma, u64 mu_gamma, unsigned gamma_bits, u64 gamma_div_2,
-                u64 neg_inv_t, u64 neg_inv_gamma, const u64* __restrict__ bcm)
+                u64 neg_inv_t, u64 neg_inv_gamma, const u64* __restrict__ bcm, size_t half_stride)
 {
     const unsigned k = blockIdx.x * kBlock + threadIdx.x;
     const unsigned r = R - 1;
-    const u64* c1 = c + (size_t)R * n;
+    c += (size_t)blockIdx.z * R * n;
+    const u64* c1 = c + half_stride;
     const unsigned mask32 = (unsigned)(t - 1);                 // `unsigned mask = t - 1`
     u64 acc_t = 0, acc_g = 0;
     for (unsigned i = 0; i < r; i++) {
@@ -229,22 +233,24 @@ hipError_t bfv_add_negate(const BfvParams& p, const BfvDevice& d, u64* pk0, cons
     return hipGetLastError();
 }
 
-hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s)
+// count > 1: a batch of ciphertexts laid out [2][count][R][n] (all first halves, then all second halves)
+hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s, unsigned count)
 {
-    k_encrypt_tail<<<dim3(p.n / kBlock, 2), kBlock, 0, s>>>(c, e, m, p.n, p.R, p.t, d.d_prime);
+    k_encrypt_tail<<<dim3(p.n / kBlock, 2, count), kBlock, 0, s>>>(c, e, m, p.n, p.R, p.t, d.d_prime, (size_t)count * p.R * p.n);
     return hipGetLastError();
 }
 
-hipError_t bfv_decrypt_scale(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s)
+hipError_t bfv_decrypt_scale(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count)
 {
-    k_decrypt_scale<<<dim3(p.n / kBlock, p.r), kBlock, 0, s>>>(c, p.n, p.R, d.d_prime);
+    k_decrypt_scale<<<dim3(p.n / kBlock, p.r, count), kBlock, 0, s>>>(c, p.n, p.R, d.d_prime, (size_t)count * p.R * p.n);
     return hipGetLastError();
 }
 
-hipError_t bfv_decrypt_round(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s)
+hipError_t bfv_decrypt_round(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count)
 {
-    k_decrypt_round<<<dim3(p.n / kBlock), kBlock, 0, s>>>(c, p.n, p.R, p.t, p.gamma, p.mu_gamma, p.gamma_bits, p.gamma_div_2,
-                                                          p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change);
+    k_decrypt_round<<<dim3(p.n / kBlock, 1, count), kBlock, 0, s>>>(c, p.n, p.R, p.t, p.gamma, p.mu_gamma, p.gamma_bits, p.gamma_div_2,
+                                                                    p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change,
+                                                                    (size_t)count * p.R * p.n);
     return hipGetLastError();
 }
 

@@ -78,16 +78,19 @@ __global__ void __launch_bounds__(kBlock) gs_stage_kernel(u64* __restrict__ a, c
 // polynomial (bpp blocks, grid-stride over the polynomial); VEC: two coefficients (16 bytes) per lane and access.
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock) pointwise_kernel(u64* __restrict__ c, const u64* __restrict__ a,
-                                                           const u64* __restrict__ b, unsigned n, unsigned division, unsigned bpp, ModSet m)
+                                                           const u64* __restrict__ b, unsigned n, unsigned division, unsigned bpp, ModSet m,
+                                                           bool shared_b, unsigned group)
 {
     const unsigned y = blockIdx.x / bpp, bx = blockIdx.x % bpp;
     const unsigned idx = y % division;
+    // one second operand per polynomial, or `division` of them per key group of `group` polynomials (0: one group)
+    b += (size_t)(shared_b ? (group ? (y / group) * division + idx : idx) : y) * n;
     const u64 q = m.q[idx], mu = m.mu[idx];
     const u32 k = m.k[idx];
     const size_t base = (size_t)y * n;
     if constexpr (VEC) {
         const ulonglong2* a2 = reinterpret_cast<const ulonglong2*>(a + base);
-        const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b + base);
+        const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b);
         ulonglong2* c2 = reinterpret_cast<ulonglong2*>(c + base);
         for (unsigned x = bx * kBlock + threadIdx.x; x < n / 2; x += bpp * kBlock) {
             const ulonglong2 u = a2[x], w = b2[x];
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(kBlock) pointwise_kernel(u64* __restrict__ c, 
             c2[x] = r;
         }
     } else {
-        for (unsigned x = bx * kBlock + threadIdx.x; x < n; x += bpp * kBlock) c[base + x] = barrett_mul(a[base + x], b[base + x], q, mu, k);
+        for (unsigned x = bx * kBlock + threadIdx.x; x < n; x += bpp * kBlock) c[base + x] = barrett_mul(a[base + x], b[x], q, mu, k);
     }
 }
 
@@ -294,14 +297,14 @@ hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned len
 }
 
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
-                            const ModSet& m, hipStream_t s)
+                            const ModSet& m, hipStream_t s, bool shared_b, unsigned group)
 {
     const bool vec = (n % 2 == 0) && ((((uintptr_t)d_c | (uintptr_t)d_a | (uintptr_t)d_b) & 15u) == 0);
     unsigned bpp = ((vec ? n / 2 : n) + kBlock - 1) / kBlock;
     if (bpp > 64) bpp = 64;                               // grid-stride inside the polynomial beyond that
     while ((unsigned long long)bpp * num > 0x7fffffffull && bpp > 1) bpp /= 2;
-    if (vec) pointwise_kernel<true><<<bpp * num, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, bpp, m);
-    else pointwise_kernel<false><<<bpp * num, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, bpp, m);
+    if (vec) pointwise_kernel<true><<<bpp * num, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, bpp, m, shared_b, group);
+    else pointwise_kernel<false><<<bpp * num, kBlock, 0, s>>>(d_c, d_a, d_b, n, division, bpp, m, shared_b, group);
     return hipGetLastError();
 }
 

@@ -204,8 +204,14 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
     return hipGetLastError();
 }
 
-hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s)
+hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
+                              bool shared_b, unsigned group)
 {
+    const unsigned plain_division = division;
+    if (shared_b) {
+        if (division > kDivisionMask || group >= (kSharedB >> kSharedGroupShift) || (group && group % division)) return hipErrorInvalidValue;
+        division |= kSharedB | (group << kSharedGroupShift);
+    }
     const TwPair* twf = reinterpret_cast<const TwPair*>(t.d_fwd);
     const TwPair* twi = reinterpret_cast<const TwPair*>(t.d_inv);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
@@ -217,11 +223,12 @@ hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, 
     case 15: return fast_mul_15(t.hl, d_a, d_bhat, twf, twi, pr, num, division, s);
     default: break;
     }
-    hipError_t e = fast_forward_batch(t, d_a, num, division, 0, s);
+    if (shared_b) return hipErrorNotSupported;           // (sizes without a fused kernel: the callers compose the three steps)
+    hipError_t e = fast_forward_batch(t, d_a, num, plain_division, 0, s);
     if (e != hipSuccess) return e;
-    e = fast_pointwise(t, d_a, d_a, d_bhat, num, division, s);
+    e = fast_pointwise(t, d_a, d_a, d_bhat, num, plain_division, s);
     if (e != hipSuccess) return e;
-    return fast_inverse_batch(t, d_a, num, division, 0, s);
+    return fast_inverse_batch(t, d_a, num, plain_division, 0, s);
 }
 
 }  // namespace mi355ntt

@@ -321,11 +321,30 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     MI355NTT_WGSTAMP(7);
 }
 
+// second-operand addressing of the fused products: one bhat polynomial per polynomial of a, or (kSharedB in the division
+// word, kernels.hpp) `division` of them per key group shared by the whole batch; strips the flag bits off `division`
+struct SharedB {
+    bool on;
+    unsigned group;
+    __device__ explicit SharedB(unsigned& division)
+        : on((division & kSharedB) != 0), group((division & ~kSharedB) >> kSharedGroupShift)
+    {
+        if (on) division &= kDivisionMask;
+    }
+    __device__ unsigned index(unsigned y, unsigned idx, unsigned division) const
+    {
+        if (!on) return y;
+        return group ? (y / group) * division + idx : idx;
+    }
+};
+__host__ __device__ inline unsigned plain_division(unsigned division) { return (division & kSharedB) ? (division & kDivisionMask) : division; }
+
 template <int HL, bool NEAR>
 __global__ void __launch_bounds__(1024, 4)
 k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
             const PrimeDev* __restrict__ primes, unsigned division, unsigned num)
 {
+    const SharedB sb(division);       // (kSharedB: bhat holds `division` polynomials per key group instead of one per polynomial)
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
@@ -347,7 +366,7 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         const TwPair* ti = twi + (size_t)idx * G::N;
         const BufRsrc tfr = make_rsrc(tf, G::N * 16u), tir = make_rsrc(ti, G::N * 16u);
         u64* poly = a + (size_t)y * G::N;
-        const BufRsrc brs = make_rsrc(bhat + (size_t)y * G::N, G::N * 8u);
+        const BufRsrc brs = make_rsrc(bhat + (size_t)sb.index(y, idx, division) * G::N, G::N * 8u);
         // ---- forward ----
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
         ct_round<LOGN, HL, 10, 4, NEAR>(v, tf, tfr, t, p);
@@ -494,6 +513,7 @@ __global__ void __launch_bounds__(64, 1)
 k_mul15_rows(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
              const PrimeDev* __restrict__ primes, unsigned division)
 {
+    const SharedB sb(division);
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
@@ -504,7 +524,7 @@ k_mul15_rows(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __
     const TwPair* ti = twi + (size_t)idx * G::N;
     const BufRsrc tfr = make_rsrc(tf, G::N * 16u), tir = make_rsrc(ti, G::N * 16u);
     const BufRsrc prs = make_rsrc(a + (size_t)y * G::N, G::N * 8u);
-    const BufRsrc brs = make_rsrc(bhat + (size_t)y * G::N, G::N * 8u);
+    const BufRsrc brs = make_rsrc(bhat + (size_t)sb.index(y, idx, division) * G::N, G::N * 8u);
     u64 v[32];
     const unsigned voff = (((t >> 5) << 10) | (t & 31u)) * 8u;                    // layout 5, as k_fwd15_rows
     static_for<32>([&](auto rc) { v[decltype(rc)::value] = buf_load_u64(prs, voff, (unsigned)decltype(rc)::value * 256u); });
@@ -547,13 +567,14 @@ __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
           const PrimeDev* __restrict__ primes, unsigned division)
 {
+    const SharedB sb(division);
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
     const unsigned y = blockIdx.x;
     const unsigned idx = y % division;
     const PrimeDev p = primes[idx];
     u64* poly = a + (size_t)y * G::N;
-    const u64* bp = bhat + (size_t)y * G::N;
+    const u64* bp = bhat + (size_t)sb.index(y, idx, division) * G::N;
     const unsigned t = threadIdx.x;
     u64 v[32];
     load_coalesced<LOGN>(v, poly, t);
@@ -705,9 +726,9 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
             dim3 g2(num * 16u), b2(64);
 #define MI355NTT_LAT3(H, N)                                                                  \
             do {                                                                             \
-                k_fwd15_cols<H, N><<<g2, b2, 0, s>>>(d_a, twf, pr, division, 0u);            \
-                k_mul15_rows<H, N><<<g2, b2, 0, s>>>(d_a, d_b, twf, twi, pr, division);      \
-                k_inv15_cols<H, N><<<g2, b2, 0, s>>>(d_a, twi, pr, division, 0u);            \
+                k_fwd15_cols<H, N><<<g2, b2, 0, s>>>(d_a, twf, pr, plain_division(division), 0u);            \
+                k_mul15_rows<H, N><<<g2, b2, 0, s>>>(d_a, d_b, twf, twi, pr, division);                  \
+                k_inv15_cols<H, N><<<g2, b2, 0, s>>>(d_a, twi, pr, plain_division(division), 0u);            \
             } while (0)
             if (near) {
                 if (h >= 6) MI355NTT_LAT3(6, true);

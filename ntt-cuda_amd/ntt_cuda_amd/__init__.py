@@ -76,6 +76,9 @@ _SIGNATURES = {
     "mi355ntt_pointwise_mul": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
     "mi355ntt_pointwise_mul_scalar": (ctypes.c_int, [vp, vp, u64, ctypes.c_uint, vp]),
     "mi355ntt_polymul_batch": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_polymul_batch_shared": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_bfv_encrypt_batch": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_uint, vp]),
+    "mi355ntt_bfv_decrypt_batch": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, vp]),
     "mi355ntt_raw_cache_clear": (ctypes.c_int, []),
     "mi355ntt_raw_uses_fast_kernels": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
     "mi355ntt_raw_trust_tables": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
@@ -344,6 +347,15 @@ class NTTContext:
     def polymul_batch(self, a, bhat, num, division=None, stream=None):
         _check(lib().mi355ntt_polymul_batch(self._h, self._p(a, num), self._p(bhat, num), int(num), int(division or self.num_primes),
                                             _stream(stream)), "mi355ntt_polymul_batch")
+
+
+    def polymul_batch_shared(self, a, bhat, num, division=None, group=0, stream=None):
+        """polymul_batch with shared second operands: polynomial y multiplies with bhat[(y // group) * division + y % division]
+        (group = 0: the whole batch is one group)"""
+        d, g = int(division or self.num_primes), int(group)
+        groups = -(-int(num) // g) if g else 1
+        _check(lib().mi355ntt_polymul_batch_shared(self._h, self._p(a, num), self._p(bhat, d * groups), int(num), d, g, _stream(stream)),
+               "mi355ntt_polymul_batch_shared")
 
 
 # --------------------------------------------------------------------------- reference-named raw API

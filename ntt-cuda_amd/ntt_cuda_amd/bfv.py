@@ -98,6 +98,20 @@ class BFVContext:
         off = self.n * (self.num_primes - 2)
         return c.reshape(-1)[off: off + self.n]
 
+    # ---- batches of ciphertexts, layout [2][count][num_primes][n]
+    def encrypt_batch(self, c, public_key, e, m, count, stream=None):
+        from . import lib, _check, _stream
+        R = self.num_primes
+        _check(lib().mi355ntt_bfv_encrypt_batch(self._h, self._p(c, 2 * R * count), self._p(public_key, 2 * R), self._p(e, 2 * R * count),
+                                                self._p(m, count), int(count), _stream(stream)), "mi355ntt_bfv_encrypt_batch")
+
+    def decrypt_batch(self, c, secret_key, count, stream=None):
+        """In place; the plaintext of ciphertext z is c.reshape(-1)[(z R + R - 2) n : ... + n]."""
+        from . import lib, _check, _stream
+        R = self.num_primes
+        _check(lib().mi355ntt_bfv_decrypt_batch(self._h, self._p(c, 2 * R * count), self._p(secret_key, R), int(count), _stream(stream)),
+               "mi355ntt_bfv_decrypt_batch")
+
     # ---- samplers and the complete drivers (SURVEY.md 8f row 3)
     @property
     def keygen_random_bytes(self):

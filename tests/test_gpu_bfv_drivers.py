@@ -108,6 +108,58 @@ def test_keygen_encrypt_decrypt_match_oracle_and_round_trip(native, oracle, gpu,
     ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nprimes,count,literal", [(4096, 3, 5, False), (32768, 4, 7, False), (32768, 60, 64, False), (4096, 0, 3, True),
+                                                     (65536, 2, 3, False)])
+def test_batched_drivers_equal_looped_single_calls(native, oracle, gpu, n, nprimes, count, literal):
+    """mi355ntt_bfv_encrypt_batch / _decrypt_batch over `count` ciphertexts (layout [2][count][R][n]) leave, for each
+    ciphertext, exactly the words the single drivers leave (those are pinned on the oracle above) -- on the fused
+    product kernels, on the three-step composition (n = 65536) and on the literal kernels (KAT-1 moduli)."""
+    import torch
+    from ntt_cuda_amd import bfv
+    if literal:
+        z = np.load(GOLD)
+        qs, psis, t, gamma = [int(x) for x in z["q"]], [int(x) for x in z["psi"]], int(z["t"]), int(z["gamma"])
+    elif nprimes == 60:
+        qs, psis, t, gamma = P.Q60 + [P.Q60_SPECIAL], P.PSI60 + [P.PSI60_SPECIAL], 1024, P.GAMMA61
+    elif n == 65536:
+        qs, psis, t, gamma = [P.EDGE_PRIMES[b][0] for b in (59, 61)], [P.EDGE_PRIMES[b][1][65536] for b in (59, 61)], 1024, P.GAMMA61
+    else:
+        (qs, psis), t, gamma = demo_moduli(n, nprimes), 1024, P.GAMMA61
+    R = len(qs)
+    ctx = bfv.BFVContext(n, qs, psis, t, gamma)
+    assert ctx.uses_literal_kernels == literal
+    smp = oracle.bfv_sample(qs, n, 5)
+    pk = np.zeros((2, R, n), dtype=np.uint64)
+    pk[1] = smp["uniform"]
+    d_sk, d_pk = native.to_device(smp["ternary"]), native.to_device(pk)
+    ctx.keygen(d_sk, d_pk, native.to_device(smp["err"]()))
+    rng = np.random.default_rng(77)
+    m = rng.integers(0, t, size=(count, n), dtype=np.uint64)
+    u = np.stack([oracle.bfv_sample(qs, n, 1000 + z_)["ternary"] for z_ in range(count)])          # [count][R][n]
+    e = np.stack([np.stack([smp["err"]() for _ in range(count)]) for _ in range(2)])                # [2][count][R][n]
+    c_batch = native.to_device(np.stack([u, u]))
+    ctx.encrypt_batch(c_batch, d_pk, native.to_device(e), native.to_device(m), count)
+    torch.cuda.synchronize()
+    got = native.to_host(c_batch).reshape(2, count, R, n)
+    singles = []
+    for z_ in range(count):
+        d_c = native.to_device(np.stack([u[z_], u[z_]]))
+        ctx.encrypt(d_c, d_pk, native.to_device(np.ascontiguousarray(e[:, z_])), native.to_device(m[z_]))
+        singles.append(d_c)
+        assert np.array_equal(native.to_host(d_c).reshape(2, R, n), got[:, z_]), z_
+    ctx.decrypt_batch(c_batch, d_sk, count)
+    torch.cuda.synchronize()
+    got = native.to_host(c_batch).reshape(2, count, R, n)
+    for z_ in range(count):
+        ctx.decrypt(singles[z_], d_sk)
+        want = native.to_host(singles[z_]).reshape(2, R, n)
+        assert np.array_equal(got[0, z_], want[0]), z_
+        assert np.array_equal(got[1, z_, : R - 1], want[1, : R - 1]), z_       # the dropped prime's c1 slot is scratch in the batch
+        assert np.array_equal(got[0, z_, R - 2], m[z_]), z_                     # and the message is back
+    ctx.close()
+
+
 def test_bfv_create_rejects_unsupported_parameters(native):
     """host-side validation happens before any GPU call"""
     import ctypes
