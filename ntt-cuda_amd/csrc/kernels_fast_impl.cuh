@@ -182,6 +182,14 @@ __device__ __forceinline__ void stagger_start()
         for (unsigned i = 0; i < ph * UNITS; i++) __builtin_amdgcn_s_sleep(32);
     }
 }
+// Order in which k_inverse15's persistent workgroups walk the batch: 1 = from the last polynomial down.  A forward
+// transform is normally followed by an inverse over the same polynomials (and the other way round): walking them in
+// opposite directions makes each kernel start on what the previous one wrote last, i.e. on what is still in the
+// memory-side cache, instead of on what a 256 MiB batch has already pushed out of it.
+#ifndef MI355NTT_INV_DESCENDING
+#define MI355NTT_INV_DESCENDING 1
+#endif
+#define MI355NTT_INV_POS(y) (MI355NTT_INV_DESCENDING ? num - 1u - (y) : (y))
 // timing experiments only (tools/kbench.hip): fold the polynomial index so the batch stays in the MALL or in L2
 #ifndef MI355NTT_POLY_SLOT
 #define MI355NTT_POLY_SLOT(y) (y)
@@ -272,16 +280,18 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
+    if (y >= num) return;
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_INV>();
     MI355NTT_WGSTAMP(1);
-    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u), 0u, lane);
+    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u), 0u, lane);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
-    unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    unsigned ymod = __builtin_amdgcn_readfirstlane(MI355NTT_INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    if (MI355NTT_INV_DESCENDING && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
     for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
         unsigned t = t0;
@@ -292,7 +302,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
+        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N;
         MI355NTT_STAMP2(it, 0);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
         gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B>(v, twp, twr, t, p);
@@ -311,7 +321,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         MI355NTT_STAMP2(it, 5);
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num)
-            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u),
+            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y + gridDim.x)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u),
                            0u, lane);
         MI355NTT_STAMP2(it, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);

@@ -64,7 +64,21 @@ __device__ __forceinline__ unsigned long long stamp_real()
 // workgroup timeline in s_memrealtime ticks (100 MHz): slot 0 kernel entry, 1 after the start stagger, 2 + i end of
 // iteration i (i < 5), 7 exit; written by thread 0 only
 __device__ unsigned long long* g_wg_buf;
-#define MI355NTT_WGSTAMP(slot) { if (threadIdx.x == 0) g_wg_buf[(size_t)blockIdx.x * 8 + (slot)] = stamp_real(); }
+// launch log: every workgroup appends its entry and exit time (all launches since the log was reset), so that the idle
+// gap between back-to-back launches -- last exit of one to first entry of the next -- can be read off
+__device__ unsigned long long* g_wg_log;          // [0]: entries logged, [1]: exits logged, [2 + i] entry i, [2 + cap + i] exit i
+constexpr unsigned kWgLogCap = 1u << 16;
+#define MI355NTT_WGSTAMP(slot)                                                                                             \
+    {                                                                                                                      \
+        if (threadIdx.x == 0) {                                                                                            \
+            const unsigned long long now_ = stamp_real();                                                                  \
+            g_wg_buf[(size_t)blockIdx.x * 8 + (slot)] = now_;                                                              \
+            if ((slot) == 0 || (slot) == 7) {                                                                              \
+                const unsigned long long k_ = atomicAdd(g_wg_log + ((slot) == 7), 1ull);                                   \
+                if (k_ < kWgLogCap) g_wg_log[2 + ((slot) == 7 ? kWgLogCap : 0u) + k_] = now_;                              \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
 #define MI355NTT_STAMP(slot)
 #else
 #define MI355NTT_STAMPV(s1, s2)

@@ -52,22 +52,34 @@ int main(int argc, char** argv)
     CK(hipMalloc(&dwg, (size_t)256 * 8 * 8));
     CK(hipMemset(dwg, 0, (size_t)256 * 8 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_buf), &dwg, sizeof(dwg)));
+    unsigned long long* dlog;
+    const size_t log_words = 2 + 2 * (size_t)kWgLogCap;
+    CK(hipMalloc(&dlog, log_words * 8));
+    CK(hipMemset(dlog, 0, log_words * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_log), &dlog, sizeof(dlog)));
 #endif
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int which = 0; which < 2; which++) {
+    // which: 0 forward, 1 inverse, 2 (KB_PAIR=1) forward then inverse over the same buffer, as bench.py's step
+    const int nwhich = getenv("KB_PAIR") ? 3 : 2;
+    for (int which = 0; which < nwhich; which++) {
         for (int i = 0; i < warm; i++) {
-            if (which == 0) (void)launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else (void)launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
+            if (which != 1) (void)launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
+            if (which != 0) (void)launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
         }
         CK(hipDeviceSynchronize());
         std::vector<float> ts;
+#ifdef MI355NTT_STAMPS
+        CK(hipMemset(dlog, 0, 16));
+#endif
         // KB_B2B = L > 1: each sample times L back-to-back launches (the queue stays full, as in bench.py), else one
         // isolated launch per sample (which includes ~10 us of host launch latency after the start event)
         const int b2b = getenv("KB_B2B") ? atoi(getenv("KB_B2B")) : 1;
         for (int i = 0; i < reps; i++) {
             CK(hipEventRecord(e0));
             for (int l = 0; l < b2b; l++) {
-                if (which == 0) (void)launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0); else (void)launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
+                if (which != 1) (void)launch_fwd<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
+                if (which != 0) (void)launch_inv<LOGN>(HLSEL, a, dtw, dp, num, 1, 0, 0);
             }
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
@@ -125,8 +137,31 @@ int main(int argc, char** argv)
             }
             stat("exit (after first entry)", [&](unsigned b) { return (double)(wg[b * 8 + 7] - t0); });
             stat("exit - last iteration end", [&](unsigned b) { return (double)(wg[b * 8 + 7] - wg[b * 8 + 1 + nit]); });
+            // launch log of the timed back-to-back launches: per launch first entry / last entry / first exit / last exit,
+            // and the gap from the last exit of the previous launch to the first entry of this one
+            std::vector<unsigned long long> lg(log_words);
+            CK(hipMemcpy(lg.data(), dlog, log_words * 8, hipMemcpyDeviceToHost));
+            const size_t ne = std::min<size_t>(lg[0], kWgLogCap), nx = std::min<size_t>(lg[1], kWgLogCap);
+            std::vector<unsigned long long> en(lg.begin() + 2, lg.begin() + 2 + ne), ex(lg.begin() + 2 + kWgLogCap, lg.begin() + 2 + kWgLogCap + nx);
+            std::sort(en.begin(), en.end()); std::sort(ex.begin(), ex.end());
+            const size_t per = nb * (which == 2 ? 1 : 1), nl = std::min(ne, nx) / per;
+            double gap = 0, span = 0, ramp = 0, tail = 0; unsigned cnt = 0;
+            for (size_t l = 1; l < nl; l++) {
+                if (b2b > 1 && l % b2b == 0) continue;               // (first launch of a sample follows an event wait, not a launch)
+                gap += (double)en[l * per] - (double)ex[l * per - 1];
+                span += (double)ex[(l + 1) * per - 1] - (double)en[l * per];
+                ramp += (double)en[(l + 1) * per - 1] - (double)en[l * per];
+                tail += (double)ex[(l + 1) * per - 1] - (double)ex[l * per];
+                cnt++;
+            }
+            if (cnt) printf("    launch log (%u back-to-back launches): gap last exit -> next first entry %.2f us, first entry -> last exit %.2f us, "
+                            "entries spread over %.2f us, exits over %.2f us\n", cnt, gap / cnt * 0.01, span / cnt * 0.01, ramp / cnt * 0.01, tail / cnt * 0.01);
         }
 #endif
+        if (which == 2) {
+            printf("pair     num=%u  median %.4f ms  min %.4f ms  => %.3f M fwd+inv pairs/s\n", num, ts[ts.size() / 2], ts[0], num / (ts[ts.size() / 2] * 1e-3) / 1e6);
+            continue;
+        }
         printf("%s  num=%u  median %.4f ms  min %.4f ms  => %.3f M transforms/s  (%.1f%% of 15.26M)\n", which ? "inverse" : "forward", num,
                ts[ts.size() / 2], ts[0], num / (ts[ts.size() / 2] * 1e-3) / 1e6, num / (ts[ts.size() / 2] * 1e-3) / 15.26e6 * 100);
     }

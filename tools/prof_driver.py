@@ -22,7 +22,32 @@ for _ in range(reps):
     ctx.forward_batch(a, batch)
     ctx.inverse_batch(a, batch)
 ctx.forward_batch(b, batch)
-for _ in range(max(1, reps // 4)):
+for _ in range(max(6, reps // 4)):
     ctx.polymul_batch(a, b, batch)
+# the latency path (one polynomial: k_fwd15_cols + k_fwd15_rows, k_inv15_rows + k_inv15_cols, and the three-launch product)
+one, two = a[:32768].clone(), b[:32768].clone()
+for _ in range(max(6, reps // 4)):
+    ctx.forward_batch(one, 1, 1)
+    ctx.inverse_batch(one, 1, 1)
+    ctx.polymul_batch(one, two, 1, 1)
+# the reference-signature entry points (checked mode: table check + guarded fast kernels), same workload
+import numpy as np
+tabs_f = torch.empty((4, 32768), dtype=torch.int64, device=dev)
+tabs_i = torch.empty((4, 32768), dtype=torch.int64, device=dev)
+for i in range(4):
+    tp, ti = ntt.fillTablePsi128(PSI60[i], Q60[i], ntt.modinv128(PSI60[i], Q60[i]), 32768)
+    tabs_f[i] = torch.from_numpy(tp.view(np.int64))
+    tabs_i[i] = torch.from_numpy(ti.view(np.int64))
+mod = ntt.Moduli(Q60)
+for _ in range(max(6, reps // 8)):
+    ntt.forwardNTT_batch(a, 32768, tabs_f, batch, 4, mod)
+    ntt.inverseNTT_batch(a, 32768, tabs_i, batch, 4, mod)
+# the 30-bit path (old/ntt_30bit.cuh) on its native kernels, same ring size
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench30 import setup30
+a30, q30, mu30, bits30, tf30, ti30 = setup30(torch, ntt, 32768, batch, dev)
+for _ in range(max(6, reps // 8)):
+    ntt.forward30(a30, 32768, q30, mu30, bits30, tf30, num=batch)
+    ntt.inverse30(a30, 32768, q30, mu30, bits30, ti30, num=batch)
 torch.cuda.synchronize()
 print("done")
