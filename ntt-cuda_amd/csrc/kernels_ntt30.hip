@@ -163,13 +163,31 @@ struct Scratch30 {
 __device__ __forceinline__ u32 shoup32_companion(u32 w, u32 q) { return (u32)(((u64)w << 32) / q); }
 
 __global__ void __launch_bounds__(256)
-k_ntt30_prepare(const u32* __restrict__ tab, unsigned n, u32 q, u32 ninv, unsigned split, Scratch30* __restrict__ sc, unsigned epoch)
+k_ntt30_prepare(const u32* __restrict__ tab, unsigned n, u32 q, u32 ninv, unsigned split, unsigned fwd, Scratch30* __restrict__ sc, unsigned epoch)
 {
+    // The round on index bits <= 4 (register field at bit 0: the forward's last round, the inverse's first) gives every
+    // thread its own twiddles: in the caller's order thread t reads cnt = 16 >> j consecutive entries of stage block j,
+    // i.e. lanes are 8 cnt bytes apart and every load instruction touches 64 cache lines.  The scratch copy stores those
+    // blocks transposed (entry k of thread t at k T + t, T = m / 32 threads), so that a load instruction reads 512
+    // consecutive bytes.  m: size the native kernel transforms (n, or n / 2 when the first stage is split off: block L of
+    // half h then is the sub-block [L (2 + h), L (2 + h) + L) of the caller's block 2 L).
+    const unsigned m = split ? n / 2 : n, logm = 31u - __clz(m), T = m / 32u;
+    const unsigned top_b0 = fwd ? (logm - 1u) % 5u : 4u;   // highest index bit of the round with the register field at bit 0
     bool bad = false;
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const u32 w = tab[i];
         if (w >= q && i != 0) bad = true;                  // (entry 0 is never read)
-        sc->tw[i] = make_uint2(w, shoup32_companion(w < q ? w : 0, q));
+        unsigned dst = i;
+        if (i >= (split ? 2u : 1u)) {
+            const unsigned l0 = 1u << (31u - __clz(i));
+            const unsigned len = split ? l0 / 2 : l0, base = l0 + ((i - l0) / len) * len, pos = (i - l0) % len;
+            const unsigned beta = logm - 1u - (31u - __clz(len));
+            if (beta <= top_b0) {
+                const unsigned cnt = 16u >> beta;
+                dst = base + (pos % cnt) * T + pos / cnt;
+            }
+        }
+        sc->tw[dst] = make_uint2(w, shoup32_companion(w < q ? w : 0, q));
     }
     if (bad) atomicMax(&sc->guard[1], epoch);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -197,6 +215,9 @@ constexpr unsigned pad32(unsigned i) { return i + (i >> 5); }
 template <int BO, int BN>
 __device__ __forceinline__ void exchange32(u32 (&v)[32], u32* img, unsigned t)
 {
+#ifdef NTT30_NOEX                                         // timing experiment: no workgroup exchange
+    return;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // DS instructions carry a 16-bit byte offset: the image (up to 132 KiB) is addressed through three bases 64 KiB apart,
     // pinned so that the compiler does not materialise one address per register
@@ -207,6 +228,10 @@ __device__ __forceinline__ void exchange32(u32 (&v)[32], u32* img, unsigned t)
     asm volatile("" : "+v"(wb1), "+v"(wb2), "+v"(rb1), "+v"(rb2));
     u32* const wb[3] = {img + wb0, img + wb1, img + wb2};
     const u32* const rb[3] = {img + rb0, img + rb1, img + rb2};
+    // The barrier that protects the image from the previous use (exchange reads or the wave-local row staging) sits in
+    // front of the writes, not behind the reads: by the time a wave gets here the others have long finished reading, so
+    // of the two barriers only the one between writes and reads is a real rendezvous.
+    __syncthreads();
     static_for<32>([&](auto rc) {
         constexpr unsigned off = pad32((unsigned)decltype(rc)::value << BO);
         wb[off / SEG][off % SEG] = v[decltype(rc)::value];
@@ -216,7 +241,78 @@ __device__ __forceinline__ void exchange32(u32 (&v)[32], u32* img, unsigned t)
         constexpr unsigned off = pad32((unsigned)decltype(rc)::value << BN);
         v[decltype(rc)::value] = rb[off / SEG][off % SEG];
     });
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Layout 0 (thread = 32 consecutive words = one 128-byte row; a wave = 8 KiB contiguous) <-> global memory with 16-byte
+// accesses, staged through the wave's own 8 KiB of the image: no workgroup barrier.  The eight 16-byte pieces of row R
+// sit at slot piece ^ ((R >> 1) & 7), so that both the row accesses (lane = row) and the transposed accesses (8 lanes
+// per row, 8 rows = 1 KiB contiguous per instruction) spread over all banks.
+__device__ __forceinline__ unsigned row_swz32(unsigned row) { return (row >> 1) & 7u; }
+__device__ __forceinline__ void lds_fence32() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void wave_store_rows32(const u32 (&v)[32], u32* img, BufRsrc dst, unsigned t)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned lane = t & 63u, wave = t >> 6;
+    char* base = reinterpret_cast<char*>(img) + wave * 8192u;
+    static_for<8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        v4u32 x;
+        x.x = v[4 * m]; x.y = v[4 * m + 1]; x.z = v[4 * m + 2]; x.w = v[4 * m + 3];
+        *reinterpret_cast<v4u32*>(base + lane * 128u + ((m ^ row_swz32(lane)) << 4)) = x;
+    });
+    lds_fence32();
+    const unsigned sw = lane & 7u, rr = lane >> 3;
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned row = 8 * k + rr;
+        const v4u32 x = *reinterpret_cast<const v4u32*>(base + row * 128u + ((sw ^ row_swz32(row)) << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave * 8192u + rr * 128u + sw * 16u, k * 1024u, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- prefetch of the next polynomial ---------------------------------------------------------------------------------
+// Vector-memory results return in order and share one counter (vmcnt) with the stores, and the compiler's waitcnt pass
+// merges the loop entry and the back edge conservatively.  With "load the first polynomial, then conditionally prefetch
+// inside the loop" it drained vmcnt to 0 inside round 1 of EVERY iteration -- waiting for the prefetch it had just issued
+// and for the previous polynomial's stores.  The loop below therefore has ONE shape on both paths: the prefetch is
+// unconditional (past the end it loads through a zero-length descriptor: out of range, returns 0, no memory traffic) and
+// the prologue issues the same number of (zero-length, dropped) stores behind the first loads as an iteration does, so
+// that "wait for the prefetch, leave the stores in flight" is the same count on entry and in steady state.
+// the row-pattern loads (x[4k .. 4k+3] = piece (lane & 7) of row 8k + (lane >> 3)), and their way into layout 0
+__device__ __forceinline__ void issue_row_loads32(u32 (&x)[32], BufRsrc src, unsigned t)
+{
+    const unsigned lane = t & 63u, wave = t >> 6;
+    const unsigned sw = lane & 7u, rr = lane >> 3;
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const v4u32 p = __builtin_amdgcn_raw_buffer_load_b128(src, wave * 8192u + rr * 128u + sw * 16u, k * 1024u, 0);
+        x[4 * k] = p.x; x[4 * k + 1] = p.y; x[4 * k + 2] = p.z; x[4 * k + 3] = p.w;
+    });
+}
+
+__device__ __forceinline__ void rows_to_layout0_32(u32 (&v)[32], u32* img, unsigned t)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned lane = t & 63u, wave = t >> 6;
+    char* base = reinterpret_cast<char*>(img) + wave * 8192u;
+    const unsigned sw = lane & 7u, rr = lane >> 3;
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const unsigned row = 8 * k + rr;
+        v4u32 x;
+        x.x = v[4 * k]; x.y = v[4 * k + 1]; x.z = v[4 * k + 2]; x.w = v[4 * k + 3];
+        *reinterpret_cast<v4u32*>(base + row * 128u + ((sw ^ row_swz32(row)) << 4)) = x;
+    });
+    lds_fence32();
+    static_for<8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const v4u32 x = *reinterpret_cast<const v4u32*>(base + lane * 128u + ((m ^ row_swz32(lane)) << 4));
+        v[4 * m] = x.x; v[4 * m + 1] = x.y; v[4 * m + 2] = x.z; v[4 * m + 3] = x.w;
+    });
+    lds_fence32();
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -229,10 +325,23 @@ __device__ __forceinline__ void load_tw32(uint2 (&W)[GROUP32], const uint2* __re
 {
     constexpr int j = FWD ? JA - G / 2 : JA + G / 2;
     constexpr unsigned len = 1u << (LOGN - 1 - (B + j));
+#ifdef NTT30_NOTW                                         // timing experiment (tools/kbench30.hip): no twiddle loads
+    static_for<GROUP32>([&](auto kc) { W[decltype(kc)::value] = make_uint2(12345u + thi, 54321u + tmul); });
+    return;
+#endif
     if constexpr (B == Geo<LOGN>::B0) {                  // first / last round: the group index does not depend on the thread -> scalar loads
         static_for<GROUP32>([&](auto kc) {
             constexpr int r0 = low_reg(j, (G % 2) * GROUP32 + decltype(kc)::value);
             W[decltype(kc)::value] = tw[len * tmul + ((unsigned)r0 >> (j + 1))];
+        });
+    } else if constexpr (B == 0) {                       // per-thread twiddles, stored transposed by k_ntt30_prepare: entry k of thread t at k T + t
+        const unsigned voff = thi * 8u;
+        const unsigned soff = len * tmul * 8u;
+        static_for<GROUP32>([&](auto kc) {
+            constexpr int r0 = low_reg(j, (G % 2) * GROUP32 + decltype(kc)::value);
+            constexpr unsigned koff = ((unsigned)r0 >> (j + 1)) * (unsigned)Geo<LOGN>::T * 8u;
+            const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(twr, voff, soff + koff, 0);
+            W[decltype(kc)::value] = make_uint2(x.x, x.y);
         });
     } else {                                             // one 32-bit lane offset, the rest in the scalar offset / immediate
         const unsigned voff = (thi << (4 - j)) * 8u;
@@ -349,6 +458,9 @@ __device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufR
     }
 }
 
+#ifndef NTT30_STAGGER
+#define NTT30_STAGGER 0
+#endif
 // One workgroup of 2^LOGN / 32 threads per polynomial of 2^LOGN words, persistent over the batch.  split: the polynomials
 // are the halves of 2^(LOGN+1)-word polynomials whose first (forward) / last (inverse) stage runs as a stage launch.
 template <int LOGN, bool FWD>
@@ -364,17 +476,41 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
     const BufRsrc twr = make_rsrc(tw, 65536u * 8u);
     // the next polynomial's coefficients are loaded into a second register set while the current one is transformed (one
     // workgroup per CU at n = 2^15: nothing else would cover the memory latency)
+    // Forward: coalesced 4-byte loads (thread t, register r = word (r << B0) | t, the layout round 1 wants), results leave
+    // from layout 0 through the wave-local row staging (16-byte stores); inverse: the mirror image.
     u32 v[32], nx[32];
-    auto issue_loads = [&](u32 (&dst)[32], unsigned y) {
-        const BufRsrc rs = make_rsrc(a + (size_t)y * n, n * 4u);
-        static_for<32>([&](auto rc) { dst[decltype(rc)::value] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
+    auto issue_loads = [&](unsigned y, bool real) {
+        const BufRsrc rs = make_rsrc(a + (size_t)y * n, real ? n * 4u : 0u);
+#if defined(NTT30_NOMEM) || defined(NTT30_NOLOAD)         // timing experiment: no polynomial traffic
+        static_for<32>([&](auto rc) { nx[decltype(rc)::value] = (t + decltype(rc)::value + y) & 0xffffu; });
+        return;
+#endif
+        if constexpr (FWD)
+            static_for<32>([&](auto rc) { nx[decltype(rc)::value] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
+        else
+            issue_row_loads32(nx, rs, t);
     };
-    if (blockIdx.x < num) issue_loads(v, blockIdx.x);
+    auto issue_stores = [&](BufRsrc prs) {                // forward: 8 x 16 bytes per thread from layout 0; inverse: 32 x 4 bytes, coalesced layout
+        if constexpr (FWD)
+            wave_store_rows32(v, img, prs, t);
+        else
+            static_for<32>([&](auto rc) { __builtin_amdgcn_raw_buffer_store_b32(v[decltype(rc)::value], prs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
+    };
+#if NTT30_STAGGER > 0
+    // every workgroup runs the same schedule; 8 phase groups per XCD start NTT30_STAGGER x 2048 cycles apart
+    if (gridDim.x >= 256u)
+        for (unsigned i = 0; i < ((blockIdx.x >> 3) & 7u) * NTT30_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
+#endif
+    if (blockIdx.x >= num) return;
+    issue_loads(blockIdx.x, true);
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = 0; });
+    issue_stores(make_rsrc(a, 0u));                       // (zero-length descriptor: dropped; see above)
     for (unsigned y = blockIdx.x; y < num; y += gridDim.x) {
         const BufRsrc prs = make_rsrc(a + (size_t)y * n, n * 4u);
         const unsigned h = split ? (y & 1u) : 0u, tmul = split ? 2u + h : 1u;
         const bool more = y + gridDim.x < num;
-        if (more) issue_loads(nx, y + gridDim.x);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = nx[decltype(rc)::value]; });
+        issue_loads(more ? y + gridDim.x : y, more);      // unconditional: one instruction stream, the last ones load nothing
         if constexpr (FWD) {
             fwd_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img);
             static_for<32>([&](auto rc) {
@@ -382,14 +518,31 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
                 u32 x = min_u32(v[r], v[r] - 2 * q);
                 v[r] = min_u32(x, x - q);
             });
-            exchange32<0, G::B0>(v, img, t);             // layout 0 (32 consecutive words per thread) -> coalesced layout
+            __syncthreads();                             // the last exchange has been read by every wave: the image is free
+#if !defined(NTT30_NOMEM) && !defined(NTT30_NOSTORE)
+            issue_stores(prs);
+#else
+            {
+                u32 x = 0;                                // (keeps every output alive)
+                static_for<32>([&](auto rc) { x ^= v[decltype(rc)::value] + decltype(rc)::value; });
+                if (x == 0xdeadbeefu) a[t] = x;
+            }
+#endif
         } else {
-            exchange32<G::B0, 0>(v, img, t);
+            __syncthreads();                             // (the previous polynomial's last exchange has been read)
+            rows_to_layout0_32(v, img, t);
             inv_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img, sc, h);
             static_for<32>([&](auto rc) { v[decltype(rc)::value] = min_u32(v[decltype(rc)::value], v[decltype(rc)::value] - q); });
+#if !defined(NTT30_NOMEM) && !defined(NTT30_NOSTORE)
+            issue_stores(prs);
+#else
+            {
+                u32 x = 0;                                // (keeps every output alive)
+                static_for<32>([&](auto rc) { x ^= v[decltype(rc)::value] + decltype(rc)::value; });
+                if (x == 0xdeadbeefu) a[t] = x;
+            }
+#endif
         }
-        static_for<32>([&](auto rc) { __builtin_amdgcn_raw_buffer_store_b32(v[decltype(rc)::value], prs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
-        if (more) static_for<32>([&](auto rc) { v[decltype(rc)::value] = nx[decltype(rc)::value]; });
     }
 }
 
@@ -485,7 +638,7 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     if (!sc) return hipErrorOutOfMemory;
     const unsigned epoch = next_epoch();
     const unsigned split = n == 65536 ? 1u : 0u;
-    k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_native, split, sc, epoch);
+    k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_native, split, FWD ? 1u : 0u, sc, epoch);
     if (split && FWD) launch_stage<true>(d_a, n, d_tab, 1, num, q, mu, bits, s, nullptr);       // stage 1 couples the two halves
     const unsigned m = split ? n / 2 : n, cnt = split ? 2 * num : num;
     switch (m) {
