@@ -385,14 +385,21 @@ __device__ __forceinline__ void ct_round32(u32 (&v)[32], const uint2* __restrict
 
 // GS stages on register bits JLO..4.  Values in [0, 2q) between stages; the stage on index bit LOGN - 1 (length 1) carries
 // m^-1: both outputs are Shoup products (the reference halves in every stage instead, old/ntt_30bit.cuh:131-196).
+// first: the round's first twiddle group when the caller keeps it in registers across polynomials (k_ntt30x: the first
+// round of every polynomial of a workgroup uses the same twiddles, and nothing is there to hide that first load behind)
 template <int LOGN, int B, int JLO>
-__device__ __forceinline__ void gs_round32(u32 (&v)[32], const uint2* __restrict__ tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, const Scratch30* sc_, unsigned h)
+__device__ __forceinline__ void gs_round32(u32 (&v)[32], const uint2* __restrict__ tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, const Scratch30* sc_, unsigned h,
+                                           const uint2 (*first)[GROUP32] = nullptr)
 {
     const u32 twoq = 2 * q;
     const unsigned thi = t >> B;
     constexpr int NG = (5 - JLO) * 2;
     uint2 W[2][GROUP32];
-    load_tw32<LOGN, B, JLO, false, 0>(W[0], tw, twr, tmul, thi);
+    if (first) {
+        static_for<GROUP32>([&](auto kc) { W[0][decltype(kc)::value] = (*first)[decltype(kc)::value]; });
+    } else {
+        load_tw32<LOGN, B, JLO, false, 0>(W[0], tw, twr, tmul, thi);
+    }
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int j = JLO + g / 2;
@@ -441,25 +448,32 @@ __device__ __forceinline__ void fwd_rounds32(u32 (&v)[32], const uint2* tw, BufR
     }
 }
 
-template <int LOGN, int RHO>
-__device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, u32* img, const Scratch30* sc, unsigned h)
+// before_last: called in front of the last round (the one whose twiddles come through scalar loads) -- the place where the
+// inverse kernel issues the next polynomial's loads: vector-memory results return in order, so a prefetch issued earlier
+// would sit in front of every twiddle load of the rounds before and turn their waits into waits for HBM
+template <int LOGN, int RHO, class F>
+__device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, u32* img, const Scratch30* sc, unsigned h,
+                                             F&& before_last, const uint2 (*first)[GROUP32])
 {
     using G = Geo<LOGN>;
     if constexpr (RHO < G::NR) {
         constexpr int LOW = 5 * RHO;
         constexpr int B = LOW < G::B0 ? LOW : G::B0;
+        if constexpr (RHO == G::NR - 1) before_last();
         if constexpr (RHO > 0) {
             constexpr int LOWP = 5 * (RHO - 1);
             constexpr int BP = LOWP < G::B0 ? LOWP : G::B0;
             exchange32<BP, B>(v, img, t);
         }
-        gs_round32<LOGN, B, LOW - B>(v, tw, twr, tmul, t, q, sc, h);
-        inv_rounds32<LOGN, RHO + 1>(v, tw, twr, tmul, t, q, img, sc, h);
+        gs_round32<LOGN, B, LOW - B>(v, tw, twr, tmul, t, q, sc, h, RHO == 0 ? first : nullptr);
+        inv_rounds32<LOGN, RHO + 1>(v, tw, twr, tmul, t, q, img, sc, h, before_last, first);
     }
 }
 
+// start stagger of the persistent workgroups (forward kernel only; measured at 4096 polynomials of 2^15 words: +3 % with
+// 2 units, nothing on the inverse)
 #ifndef NTT30_STAGGER
-#define NTT30_STAGGER 0
+#define NTT30_STAGGER 2
 #endif
 // One workgroup of 2^LOGN / 32 threads per polynomial of 2^LOGN words, persistent over the batch.  split: the polynomials
 // are the halves of 2^(LOGN+1)-word polynomials whose first (forward) / last (inverse) stage runs as a stage launch.
@@ -498,10 +512,14 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
     };
 #if NTT30_STAGGER > 0
     // every workgroup runs the same schedule; 8 phase groups per XCD start NTT30_STAGGER x 2048 cycles apart
-    if (gridDim.x >= 256u)
+    if (FWD && gridDim.x >= 256u)
         for (unsigned i = 0; i < ((blockIdx.x >> 3) & 7u) * NTT30_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
 #endif
     if (blockIdx.x >= num) return;
+    // inverse: the first twiddle group of the first round stays in registers (every polynomial of this workgroup belongs to
+    // the same half when the transform is split: the grid is even whenever a workgroup sees more than one polynomial)
+    [[maybe_unused]] uint2 W0[GROUP32];
+    if constexpr (!FWD) load_tw32<LOGN, 0, 0, false, 0>(W0, tw, twr, split ? 2u + (blockIdx.x & 1u) : 1u, t);
     issue_loads(blockIdx.x, true);
     static_for<32>([&](auto rc) { v[decltype(rc)::value] = 0; });
     issue_stores(make_rsrc(a, 0u));                       // (zero-length descriptor: dropped; see above)
@@ -510,8 +528,11 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
         const unsigned h = split ? (y & 1u) : 0u, tmul = split ? 2u + h : 1u;
         const bool more = y + gridDim.x < num;
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = nx[decltype(rc)::value]; });
-        issue_loads(more ? y + gridDim.x : y, more);      // unconditional: one instruction stream, the last ones load nothing
+        // the prefetch of the next polynomial (unconditional: one instruction stream; past the end it loads nothing) goes in
+        // front of the round with scalar twiddle loads: the forward's first, the inverse's last
+        auto prefetch = [&]() { issue_loads(more ? y + gridDim.x : y, more); };
         if constexpr (FWD) {
+            prefetch();
             fwd_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img);
             static_for<32>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -531,7 +552,7 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
         } else {
             __syncthreads();                             // (the previous polynomial's last exchange has been read)
             rows_to_layout0_32(v, img, t);
-            inv_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img, sc, h);
+            inv_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img, sc, h, prefetch, &W0);
             static_for<32>([&](auto rc) { v[decltype(rc)::value] = min_u32(v[decltype(rc)::value], v[decltype(rc)::value] - q); });
 #if !defined(NTT30_NOMEM) && !defined(NTT30_NOSTORE)
             issue_stores(prs);
