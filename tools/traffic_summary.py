@@ -7,7 +7,7 @@ def mean_by_kernel(pattern):
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(out, pattern, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+            acc[row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 BYTES = 512 << 20
 res = {"units": "FETCH_SIZE/WRITE_SIZE are reported in KiB by rocprofv3", "calibration": {}, "kernels": {}}
@@ -22,3 +22,23 @@ for k in nf:
         res["kernels"][k.strip()] = {"fetch_KiB_raw": nf[k], "write_KiB_raw": nw.get(k)}
 print(json.dumps(res, indent=1))
 json.dump(res, open(os.path.join(out, "traffic_raw.json"), "w"), indent=1)
+
+# the committed form (profiles/traffic_rNN.json, read by bench.py): bytes per launch with the gfx950 FETCH_SIZE correction
+# the calibration copies establish (x 2), against the algorithmic bytes of one launch of the profiled workload
+ALG = {"k_forward15": 1024 * 524288, "k_inverse15": 1024 * 524288, "k_polymul15": 1024 * 786432,
+       "k_ntt30x<15, true>": 1024 * 262144, "k_ntt30x<15, false>": 1024 * 262144}
+fs = [c["fetch_scale"] for c in res["calibration"].values()]
+scale = round(sum(fs) / len(fs)) if fs else 2
+final = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_traffic.sh), python3 tools/prof_driver.py "
+                 "1024 3: n=32768, 4x60-bit primes, 1024 polynomials per launch (30-bit kernels: 1024 polynomials of 32768 words). "
+                 "rocprofv3 reports KiB. Calibration on known 512 MiB copies (tools/calib_copy.hip) on the same box gives the FETCH_SIZE "
+                 "scale (%d: FETCH_SIZE reads half of the bytes on gfx950, as MI355X_MICROARCH.md says), WRITE_SIZE is exact. "
+                 "hbm_bytes_per_launch = (%d*FETCH_SIZE + WRITE_SIZE)*1024; Infinity-Cache hits are included in FETCH_SIZE." % (scale, scale),
+         "calibration": res["calibration"]}
+for k, v in res["kernels"].items():
+    for name, alg in ALG.items():
+        if ("::" + name) in k and v.get("write_KiB_raw") is not None:
+            hbm = (scale * v["fetch_KiB_raw"] + v["write_KiB_raw"]) * 1024
+            final[name.replace("<15, true>", "_fwd15").replace("<15, false>", "_inv15")] = dict(
+                v, hbm_bytes_per_launch=hbm, algorithmic_bytes_per_launch=alg, ratio=hbm / alg)
+json.dump(final, open(os.path.join(out, "traffic_final.json"), "w"), indent=1)
