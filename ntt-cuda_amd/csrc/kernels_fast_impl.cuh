@@ -44,7 +44,7 @@ __device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restr
 // stores of the current one, so the write drain, the dispatch gap and the read latency overlap.
 
 // ---- forward: natural -> bit-reversed, canonical ------------------------------------------------
-template <int LOGN, int HL>
+template <int LOGN, int HL, bool NEAR>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
           unsigned prime_base, unsigned num)
@@ -68,8 +68,8 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         const TwPair* twp = tw + (size_t)idx * G::N;
         u64* poly = a + (size_t)y * G::N;
         MI355NTT_STAMP(0);
-        forward_core<LOGN, HL>(v, twp, t, p, lds);
-        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q(v[decltype(rc)::value], p), p.q); });
+        forward_core<LOGN, HL, NEAR>(v, twp, t, p, lds);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMP(6);
         exchange<LOGN, 0, G::B0>(v, lds, t);
         MI355NTT_STAMP(7);
@@ -81,7 +81,7 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 }
 
 // ---- inverse: bit-reversed -> natural, scaled by n^-1, canonical --------------------------------
-template <int LOGN, int HL>
+template <int LOGN, int HL, bool NEAR>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
           unsigned prime_base, unsigned num)
@@ -107,8 +107,8 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         MI355NTT_STAMP(0);
         exchange<LOGN, G::B0, 0>(v, lds, t);
         MI355NTT_STAMP(1);
-        inverse_core<LOGN, HL>(v, twp, t, p, lds);
-        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL>(v[decltype(rc)::value], p); });
+        inverse_core<LOGN, HL, NEAR>(v, twp, t, p, lds);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP(8);
         store_coalesced<LOGN>(v, poly, t);
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
@@ -572,7 +572,7 @@ inline unsigned latency_path_max_polys()
 }
 
 // ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
-template <int LOGN, int HL>
+template <int LOGN, int HL, bool NEAR>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)
 k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
           const PrimeDev* __restrict__ primes, unsigned division)
@@ -588,21 +588,21 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     const unsigned t = threadIdx.x;
     u64 v[32];
     load_coalesced<LOGN>(v, poly, t);
-    forward_core<LOGN, HL>(v, twf + (size_t)idx * G::N, t, p, lds);
+    forward_core<LOGN, HL, NEAR>(v, twf + (size_t)idx * G::N, t, p, lds);
     // layout 0: this thread holds NTT values 32t .. 32t+31; the inverse starts from the same layout
     const BufRsrc brs = make_rsrc(bp, G::N * 8u);
 #pragma unroll
     for (int r = 0; r < 32; r += 2) {
         const TwPair bb = buf_load_tw(brs, t * 256u, (unsigned)r * 8u);      // two consecutive words of bhat
-        const u64 x0 = canon_2q(reduce_2q(v[r], p), p.q);
-        const u64 x1 = canon_2q(reduce_2q(v[r + 1], p), p.q);
+        const u64 x0 = canon_2q(reduce_2q_sel<NEAR>(v[r], p), p.q);
+        const u64 x1 = canon_2q(reduce_2q_sel<NEAR>(v[r + 1], p), p.q);
         v[r] = barrett_mul(x0, bb.w, p.q, p.mu, p.k);          // poly_arithmetic.cuh:36-66, Algorithm 7
         v[r + 1] = barrett_mul(x1, bb.wp, p.q, p.mu, p.k);
         if ((r & 6) == 6) __builtin_amdgcn_sched_barrier(0);
     }
-    inverse_core<LOGN, HL>(v, twi + (size_t)idx * G::N, t, p, lds);
+    inverse_core<LOGN, HL, NEAR>(v, twi + (size_t)idx * G::N, t, p, lds);
 #pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL>(v[r], p);
+    for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL, NEAR>(v[r], p);
     store_coalesced<LOGN>(v, poly, t);
 }
 
@@ -669,10 +669,17 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
             else k_forward15<2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         }
     } else {
+        const bool near = (hl & 16) != 0;
         hl &= 15;
-        if (hl >= 6) k_forward<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else if (hl >= 4) k_forward<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else k_forward<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        if (near) {
+            if (hl >= 6) k_forward<LOGN, 6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (hl >= 4) k_forward<LOGN, 4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_forward<LOGN, 2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        } else {
+            if (hl >= 6) k_forward<LOGN, 6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (hl >= 4) k_forward<LOGN, 4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_forward<LOGN, 2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        }
     }
 #endif
     return hipGetLastError();
@@ -715,10 +722,17 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
             else k_inverse15<2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         }
     } else {
+        const bool near = (hl & 16) != 0;
         hl &= 15;
-        if (hl >= 6) k_inverse<LOGN, 6><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else if (hl >= 4) k_inverse<LOGN, 4><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        else k_inverse<LOGN, 2><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        if (near) {
+            if (hl >= 6) k_inverse<LOGN, 6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (hl >= 4) k_inverse<LOGN, 4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_inverse<LOGN, 2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        } else {
+            if (hl >= 6) k_inverse<LOGN, 6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else if (hl >= 4) k_inverse<LOGN, 4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+            else k_inverse<LOGN, 2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        }
     }
 #endif
     return hipGetLastError();
@@ -762,11 +776,18 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
             else k_polymul15<2, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
         }
     } else {
+        const bool near = (hl & 16) != 0;
         hl &= 15;
         dim3 g(num), b(Geo<LOGN>::T);
-        if (hl >= 6) k_polymul<LOGN, 6><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-        else if (hl >= 4) k_polymul<LOGN, 4><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-        else k_polymul<LOGN, 2><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+        if (near) {
+            if (hl >= 6) k_polymul<LOGN, 6, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+            else if (hl >= 4) k_polymul<LOGN, 4, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+            else k_polymul<LOGN, 2, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+        } else {
+            if (hl >= 6) k_polymul<LOGN, 6, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+            else if (hl >= 4) k_polymul<LOGN, 4, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+            else k_polymul<LOGN, 2, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
+        }
     }
     return hipGetLastError();
 }

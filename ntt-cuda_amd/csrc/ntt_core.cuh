@@ -815,7 +815,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
 // ------------------------------------------------------------------------------------------------
 // whole transforms on registers.  Entry and exit layout: B0 (coalesced: i = (r << B0) | t).
 // ------------------------------------------------------------------------------------------------
-template <int LOGN, int HL, int RHO>
+template <int LOGN, int HL, int RHO, bool NEAR = false>
 __device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds)
 {
     using G = Geo<LOGN>;
@@ -828,20 +828,20 @@ __device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             exchange<LOGN, BP, B>(v, lds, t);
             MI355NTT_STAMP(2 * RHO);
         }
-        ct_round<LOGN, HL, B, TOP - B>(v, tw, twr, t, p);
+        ct_round<LOGN, HL, B, TOP - B, NEAR>(v, tw, twr, t, p);
         MI355NTT_STAMP(2 * RHO + 1);
-        fwd_rounds<LOGN, HL, RHO + 1>(v, tw, twr, t, p, lds);
+        fwd_rounds<LOGN, HL, RHO + 1, NEAR>(v, tw, twr, t, p, lds);
     }
 }
 
 // natural-order coefficients in (layout B0, canonical) -> bit-reversed NTT values, left in layout 0, in [0, B*q)
-template <int LOGN, int HL>
+template <int LOGN, int HL, bool NEAR = false>
 __device__ __forceinline__ void forward_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
 {
-    fwd_rounds<LOGN, HL, 0>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
+    fwd_rounds<LOGN, HL, 0, NEAR>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
 }
 
-template <int LOGN, int HL, int RHO>
+template <int LOGN, int HL, int RHO, bool NEAR = false>
 __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds)
 {
     using G = Geo<LOGN>;
@@ -854,17 +854,17 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             exchange<LOGN, BP, B>(v, lds, t);
             MI355NTT_STAMP(2 * RHO + 2);
         }
-        gs_round<LOGN, HL, B, LOW - B>(v, tw, twr, t, p);
+        gs_round<LOGN, HL, B, LOW - B, NEAR>(v, tw, twr, t, p);
         MI355NTT_STAMP(2 * RHO + 3);
-        inv_rounds<LOGN, HL, RHO + 1>(v, tw, twr, t, p, lds);
+        inv_rounds<LOGN, HL, RHO + 1, NEAR>(v, tw, twr, t, p, lds);
     }
 }
 
 // bit-reversed values in layout 0 (any representative below 2q... see callers) -> coefficients in layout B0, in [0, TQ*q)
-template <int LOGN, int HL>
+template <int LOGN, int HL, bool NEAR = false>
 __device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
 {
-    inv_rounds<LOGN, HL, 0>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
+    inv_rounds<LOGN, HL, 0, NEAR>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
 }
 
 // [0, TQ*q) -> [0, q).  Near-2^k primes: the 3-instruction fold brings [0, 4q) below 2q, so one compare/select pair

@@ -14,10 +14,11 @@ def find_psi(q, n):
             return psi
 
 dev = torch.device("cuda", 0)
-def timeit(f, reps=10):
-    for _ in range(2): f()
-    torch.cuda.synchronize()
+def timeit(f, reps=40):
+    # untimed pre-warm flowing straight into the timed launches: a region timed right after a host synchronisation reads
+    # the clock ramp (up to 30 % low), not the kernels
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(100): f()
     e0.record()
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
