@@ -249,6 +249,7 @@ __device__ __forceinline__ void exchange32(u32 (&v)[32], u32* img, unsigned t)
 // sit at slot piece ^ ((R >> 1) & 7), so that both the row accesses (lane = row) and the transposed accesses (8 lanes
 // per row, 8 rows = 1 KiB contiguous per instruction) spread over all banks.
 __device__ __forceinline__ unsigned row_swz32(unsigned row) { return (row >> 1) & 7u; }
+__device__ __forceinline__ unsigned row_swz32_store(unsigned row) { return row & 7u; }      // (ntt_core.cuh, row_swz_store)
 __device__ __forceinline__ void lds_fence32() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ void wave_store_rows32(const u32 (&v)[32], u32* img, BufRsrc dst, unsigned t)
@@ -260,14 +261,14 @@ __device__ __forceinline__ void wave_store_rows32(const u32 (&v)[32], u32* img, 
         constexpr int m = decltype(mc)::value;
         v4u32 x;
         x.x = v[4 * m]; x.y = v[4 * m + 1]; x.z = v[4 * m + 2]; x.w = v[4 * m + 3];
-        *reinterpret_cast<v4u32*>(base + lane * 128u + ((m ^ row_swz32(lane)) << 4)) = x;
+        *reinterpret_cast<v4u32*>(base + lane * 128u + ((m ^ row_swz32_store(lane)) << 4)) = x;
     });
     lds_fence32();
     const unsigned sw = lane & 7u, rr = lane >> 3;
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const unsigned row = 8 * k + rr;
-        const v4u32 x = *reinterpret_cast<const v4u32*>(base + row * 128u + ((sw ^ row_swz32(row)) << 4));
+        const v4u32 x = *reinterpret_cast<const v4u32*>(base + row * 128u + ((sw ^ row_swz32_store(row)) << 4));
         __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave * 8192u + rr * 128u + sw * 16u, k * 1024u, 0);
     });
     __builtin_amdgcn_sched_barrier(0);
