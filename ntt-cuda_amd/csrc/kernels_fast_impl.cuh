@@ -358,12 +358,16 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    u64* slice = lds + wave * WAVE_SLICE_WORDS;
+    // thread-derived values are rebuilt where they are used (wave index in an SGPR, lane index from v_mbcnt), as in
+    // k_forward15: kept live across the polynomial loop they were spills
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+s"(wave_s));
+    auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
+    u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
     stagger_start<MI355NTT_STAGGER_MUL>();
-    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    load_coalesced<LOGN>(v, a + (size_t)y * G::N, fresh_t());
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -376,43 +380,44 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         const TwPair* ti = twi + (size_t)idx * G::N;
         const BufRsrc tfr = make_rsrc(tf, G::N * 16u), tir = make_rsrc(ti, G::N * 16u);
         u64* poly = a + (size_t)y * G::N;
-        const BufRsrc brs = make_rsrc(bhat + (size_t)sb.index(y, idx, division) * G::N, G::N * 8u);
+        // (the wave's 16 KiB chunk of bhat goes into the descriptor's base)
+        const BufRsrc brs = make_rsrc(bhat + (size_t)sb.index(y, idx, division) * G::N + wave_s * 2048u, 16384u);
         // ---- forward ----
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
-        ct_round<LOGN, HL, 10, 4, NEAR>(v, tf, tfr, t, p);
+        ct_round<LOGN, HL, 10, 4, NEAR>(v, tf, tfr, 0u, p);   // (round 1 reads no thread-derived value)
         __syncthreads();
-        exchange<LOGN, 10, 5>(v, lds, t);
+        exchange<LOGN, 10, 5>(v, lds, fresh_t());
         MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
-        ct_round<LOGN, HL, 5, 4, NEAR>(v, tf, tfr, t, p);
-        wave_transpose_5_to_0(v, slice, lane);
+        ct_round<LOGN, HL, 5, 4, NEAR>(v, tf, tfr, fresh_t(), p);
+        wave_transpose_5_to_0(v, slice, fresh_lane_id());
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
-        ct_round<LOGN, HL, 0, 4, NEAR>(v, tf, tfr, t, p);
+        ct_round<LOGN, HL, 0, 4, NEAR>(v, tf, tfr, fresh_t(), p);
         // ---- pointwise product with bhat, streamed 16 words per lane at a time (layout 0 on both sides) ----
         {
             u64 bb[16];
-            wave_load_rows_half<0>(bb, slice, brs, wave * 16384u, lane);
+            wave_load_rows_half<0>(bb, slice, brs, 0u, 0u);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[r], p), p.q), bb[r], p.q, p.mu, p.k);   // poly_arithmetic.cuh:36-66
             });
-            wave_load_rows_half<1>(bb, slice, brs, wave * 16384u, lane);
+            wave_load_rows_half<1>(bb, slice, brs, 0u, 0u);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[16 + r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[16 + r], p), p.q), bb[r], p.q, p.mu, p.k);
             });
         }
         // ---- inverse ----
-        gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, t, p);
-        wave_transpose_0_to_5(v, slice, lane);
+        gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, fresh_t(), p);
+        wave_transpose_0_to_5(v, slice, fresh_lane_id());
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-        gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, t, p);
+        gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, fresh_t(), p);
         __syncthreads();
-        exchange<LOGN, 5, 10>(v, lds, t);
+        exchange<LOGN, 5, 10>(v, lds, fresh_t());
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, t, p);
+        gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, fresh_t(), p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
-        store_coalesced<LOGN>(v, poly, t);
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        store_coalesced<LOGN>(v, poly, fresh_t());
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, fresh_t());
     }
 }
 

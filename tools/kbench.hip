@@ -137,6 +137,29 @@ int main(int argc, char** argv)
             }
             stat("exit (after first entry)", [&](unsigned b) { return (double)(wg[b * 8 + 7] - t0); });
             stat("exit - last iteration end", [&](unsigned b) { return (double)(wg[b * 8 + 7] - wg[b * 8 + 1 + nit]); });
+            if (getenv("KB_WGDUMP")) {      // per workgroup: XCD (blockIdx % 8), stagger phase, iteration durations, exit time (us)
+                for (int x = 0; x < 8; x++) {
+                    double sum[6] = {0, 0, 0, 0, 0, 0}; unsigned cnt2 = 0;
+                    for (unsigned b = x; b < nb; b += 8) {
+                        for (int i = 0; i < nit; i++) sum[i] += (double)(wg[b * 8 + 2 + i] - (i ? wg[b * 8 + 1 + i] : wg[b * 8 + 1])) * 0.01;
+                        sum[5] += (double)(wg[b * 8 + 7] - t0) * 0.01; cnt2++;
+                    }
+                    printf("    xcd %d: mean iteration us", x);
+                    for (int i = 0; i < nit; i++) printf(" %6.2f", sum[i] / cnt2);
+                    printf("   mean exit %7.2f\n", sum[5] / cnt2);
+                }
+                for (int ph = 0; ph < 8; ph++) {
+                    double sum[6] = {0, 0, 0, 0, 0, 0}, mx = 0; unsigned cnt2 = 0;
+                    for (unsigned b = 0; b < nb; b++) {
+                        if (((b >> 3) & 7u) != (unsigned)ph) continue;
+                        for (int i = 0; i < nit; i++) sum[i] += (double)(wg[b * 8 + 2 + i] - (i ? wg[b * 8 + 1 + i] : wg[b * 8 + 1])) * 0.01;
+                        const double ex = (double)(wg[b * 8 + 7] - t0) * 0.01; sum[5] += ex; mx = std::max(mx, ex); cnt2++;
+                    }
+                    printf("    phase %d: mean iteration us", ph);
+                    for (int i = 0; i < nit; i++) printf(" %6.2f", sum[i] / cnt2);
+                    printf("   mean exit %7.2f  max exit %7.2f\n", sum[5] / cnt2, mx);
+                }
+            }
             // launch log of the timed back-to-back launches: per launch first entry / last entry / first exit / last exit,
             // and the gap from the last exit of the previous launch to the first entry of this one
             std::vector<unsigned long long> lg(log_words);
