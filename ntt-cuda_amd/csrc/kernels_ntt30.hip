@@ -479,7 +479,7 @@ __device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufR
 // One workgroup of 2^LOGN / 32 threads per polynomial of 2^LOGN words, persistent over the batch.  split: the polynomials
 // are the halves of 2^(LOGN+1)-word polynomials whose first (forward) / last (inverse) stage runs as a stage launch.
 template <int LOGN, bool FWD>
-__global__ void __launch_bounds__(Geo<LOGN>::T)
+__global__ void __launch_bounds__(Geo<LOGN>::T, 4)       // 128 VGPRs: four waves per SIMD, i.e. as many workgroups per CU as the LDS image admits
 k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned num, unsigned split)
 {
     if (sc->guard[0] == sc->guard[1]) return;            // a table entry >= q: the literal leg transforms the data
@@ -601,7 +601,7 @@ unsigned next_epoch()
 template <int LOGN, bool FWD>
 void launch_native(u32* d_a, const Scratch30* sc, u32 q, unsigned num, unsigned split, hipStream_t s)
 {
-    const unsigned lds = pad32(1u << LOGN) * 4u, per_cu_lds = 163840u / lds, per_cu_waves = 32u / (Geo<LOGN>::T / 64u);
+    const unsigned lds = pad32(1u << LOGN) * 4u, per_cu_lds = 163840u / lds, per_cu_waves = 16u / (Geo<LOGN>::T / 64u);   // 4 waves/SIMD at 128 VGPRs
     unsigned per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     if (per_cu < 1) per_cu = 1;
     const unsigned cap = 256u * per_cu;
