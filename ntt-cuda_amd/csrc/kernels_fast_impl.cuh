@@ -165,21 +165,31 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 // Measured on k_forward15 (tools/kbench.hip, warm): +7...10 % for 256...1024 polynomials with UNITS = 1 (at most
 // 6 us of delay), fading to +2 % at 2048 and nothing at 4096, where the workgroups drift apart by themselves; nothing
 // on k_inverse15 and -3 % on k_polymul15 at 256 polynomials, which are left alone.
+// Round 2 (inverse walking the batch downwards, profiles/r02_stagger_retune.txt): when a workgroup walks more than one
+// polynomial, 2 units on BOTH kernels give +2.5 % pairs at 512, +4 % at 768, +1.5...3 % at 1024, nothing from 2048 up; with one
+// polynomial per workgroup the delay is pure tail (-4 % at 2 units), so those launches keep 1 unit (forward) / none (inverse).
 #ifndef MI355NTT_STAGGER_FWD
 #define MI355NTT_STAGGER_FWD 1
 #endif
 #ifndef MI355NTT_STAGGER_INV
 #define MI355NTT_STAGGER_INV 0
 #endif
+#ifndef MI355NTT_STAGGER_FWD_MULTI
+#define MI355NTT_STAGGER_FWD_MULTI 2
+#endif
+#ifndef MI355NTT_STAGGER_INV_MULTI
+#define MI355NTT_STAGGER_INV_MULTI 2
+#endif
 #ifndef MI355NTT_STAGGER_MUL
 #define MI355NTT_STAGGER_MUL 0
 #endif
-template <int UNITS>
-__device__ __forceinline__ void stagger_start()
+template <int UNITS, int UNITS_MULTI = UNITS>
+__device__ __forceinline__ void stagger_start(bool multi = false)
 {
-    if constexpr (UNITS > 0) {
+    if constexpr (UNITS > 0 || UNITS_MULTI > 0) {
         const unsigned ph = (blockIdx.x >> 3) & 7u;
-        for (unsigned i = 0; i < ph * UNITS; i++) __builtin_amdgcn_s_sleep(32);
+        const unsigned n = ph * (multi ? (unsigned)UNITS_MULTI : (unsigned)UNITS);
+        for (unsigned i = 0; i < n; i++) __builtin_amdgcn_s_sleep(32);
     }
 }
 // Order in which k_inverse15's persistent workgroups walk the batch: 1 = from the last polynomial down.  A forward
@@ -218,7 +228,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64 v[32];
     unsigned y = blockIdx.x;
     MI355NTT_WGSTAMP(0);
-    stagger_start<MI355NTT_STAGGER_FWD>();
+    stagger_start<MI355NTT_STAGGER_FWD, MI355NTT_STAGGER_FWD_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
     load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, fresh_t());
     [[maybe_unused]] int it = 0;
@@ -282,7 +292,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     unsigned y = blockIdx.x;
     if (y >= num) return;
     MI355NTT_WGSTAMP(0);
-    stagger_start<MI355NTT_STAGGER_INV>();
+    stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
     wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u), 0u, lane);
     [[maybe_unused]] int it = 0;
