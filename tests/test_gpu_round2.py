@@ -257,3 +257,43 @@ def test_context_calls_run_on_the_context_device(native, gpu):
         native.NTTContext(2048, [P.REF_PARAMS[2048][0]], [P.REF_PARAMS[2048][1]], device=63)
     assert torch.cuda.current_device() == before
     ctx.close()
+
+
+# ------------------------------------------------------------------------------ fused product with shared second operands
+@pytest.mark.parametrize("n,qs_name,num,group", [(32768, "Q60", 22, 8), (32768, "Q60", 300, 0), (4096, "Q60", 13, 4), (2048, "Q60", 9, 0),
+                                                  (65536, "EDGE", 6, 2), (4096, "KAT", 7, 0)])
+def test_polymul_batch_shared_matches_oracle(native, oracle, gpu, n, qs_name, num, group):
+    """mi355ntt_polymul_batch_shared: polynomial y multiplies with bhat[(y // group) * division + y % division] (group 0: one
+    group).  Against the oracle's forward -> pointwise -> inverse (bfv_encryption.cuh:268-271 with one key for many
+    ciphertexts), ragged batches, on the fused kernels (persistent and latency path), the split n = 2^16 composition and
+    the literal kernels (KAT-1 moduli)."""
+    if qs_name == "Q60":
+        qs = P.Q60
+        psis = [pow(psi, 32768 // n, q) for psi, q in zip(P.PSI60, qs)]
+    elif qs_name == "EDGE":
+        qs, psis = [P.EDGE_PRIMES[b][0] for b in (59, 61)], [P.EDGE_PRIMES[b][1][n] for b in (59, 61)]
+    else:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat1_decryption_n4096.npz"))
+        qs, psis = [int(x) for x in z["q"]], [int(x) for x in z["psi"]]
+    D = len(qs)
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    assert ctx.uses_literal_kernels == (qs_name == "KAT")
+    groups = -(-num // group) if group else 1
+    a = oracle.synth_batch(n, num, qs, 31)
+    keys = oracle.forward_batch(oracle.synth_batch(n, groups * D, qs, 32), prm)                 # NTT-domain operands, prime y % D
+    b_full = np.stack([keys[((y // group) if group else 0) * D + y % D] for y in range(num)])
+    want = oracle.inverse_batch(oracle.pointwise_batch(oracle.forward_batch(a, prm), b_full, prm), prm)
+    d_a = dev(native, a)
+    ctx.polymul_batch_shared(d_a, dev(native, keys), num, D, group)
+    assert np.array_equal(host(native, d_a), want)
+    ctx.close()
+
+
+def test_polymul_batch_shared_rejects_bad_groups(native, gpu):
+    ctx = native.NTTContext(4096, P.Q60, [pow(psi, 8, q) for psi, q in zip(P.PSI60, P.Q60)])
+    import torch
+    a = torch.zeros((8, 4096), dtype=torch.int64, device=gpu)
+    with pytest.raises(native.NTTError):
+        ctx.polymul_batch_shared(a, a, 8, 4, 6)          # group not a multiple of division
+    ctx.close()
