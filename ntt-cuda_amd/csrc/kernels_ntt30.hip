@@ -320,11 +320,14 @@ __device__ __forceinline__ void rows_to_layout0_32(u32 (&v)[32], u32* img, unsig
 // Twiddles of butterfly group G of a round: 8 butterflies per group, two groups per stage, the loads run one group ahead
 // (a ring of 2 x 8 pairs = 32 VGPRs); scheduling fences around each group keep the compiler from hoisting a whole round's
 // loads (which cost the first version 144 VGPRs and spills).
-constexpr int GROUP32 = 8;
+#ifndef NTT30_GROUP
+#define NTT30_GROUP 8
+#endif
+constexpr int GROUP32 = NTT30_GROUP, GPS32 = 16 / GROUP32;      // butterflies per twiddle group, groups per stage
 template <int LOGN, int B, int JA, bool FWD, int G>
 __device__ __forceinline__ void load_tw32(uint2 (&W)[GROUP32], const uint2* __restrict__ tw, BufRsrc twr, unsigned tmul, unsigned thi)
 {
-    constexpr int j = FWD ? JA - G / 2 : JA + G / 2;
+    constexpr int j = FWD ? JA - G / GPS32 : JA + G / GPS32;
     constexpr unsigned len = 1u << (LOGN - 1 - (B + j));
 #ifdef NTT30_NOTW                                         // timing experiment (tools/kbench30.hip): no twiddle loads
     static_for<GROUP32>([&](auto kc) { W[decltype(kc)::value] = make_uint2(12345u + thi, 54321u + tmul); });
@@ -332,14 +335,14 @@ __device__ __forceinline__ void load_tw32(uint2 (&W)[GROUP32], const uint2* __re
 #endif
     if constexpr (B == Geo<LOGN>::B0) {                  // first / last round: the group index does not depend on the thread -> scalar loads
         static_for<GROUP32>([&](auto kc) {
-            constexpr int r0 = low_reg(j, (G % 2) * GROUP32 + decltype(kc)::value);
+            constexpr int r0 = low_reg(j, (G % GPS32) * GROUP32 + decltype(kc)::value);
             W[decltype(kc)::value] = tw[len * tmul + ((unsigned)r0 >> (j + 1))];
         });
     } else if constexpr (B == 0) {                       // per-thread twiddles, stored transposed by k_ntt30_prepare: entry k of thread t at k T + t
         const unsigned voff = thi * 8u;
         const unsigned soff = len * tmul * 8u;
         static_for<GROUP32>([&](auto kc) {
-            constexpr int r0 = low_reg(j, (G % 2) * GROUP32 + decltype(kc)::value);
+            constexpr int r0 = low_reg(j, (G % GPS32) * GROUP32 + decltype(kc)::value);
             constexpr unsigned koff = ((unsigned)r0 >> (j + 1)) * (unsigned)Geo<LOGN>::T * 8u;
             const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(twr, voff, soff + koff, 0);
             W[decltype(kc)::value] = make_uint2(x.x, x.y);
@@ -348,7 +351,7 @@ __device__ __forceinline__ void load_tw32(uint2 (&W)[GROUP32], const uint2* __re
         const unsigned voff = (thi << (4 - j)) * 8u;
         const unsigned soff = len * tmul * 8u;
         static_for<GROUP32>([&](auto kc) {
-            constexpr int r0 = low_reg(j, (G % 2) * GROUP32 + decltype(kc)::value);
+            constexpr int r0 = low_reg(j, (G % GPS32) * GROUP32 + decltype(kc)::value);
             const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(twr, voff + ((unsigned)r0 >> (j + 1)) * 8u, soff, 0);
             W[decltype(kc)::value] = make_uint2(x.x, x.y);
         });
@@ -363,17 +366,17 @@ __device__ __forceinline__ void ct_round32(u32 (&v)[32], const uint2* __restrict
 {
     const u32 twoq = 2 * q;
     const unsigned thi = t >> B;
-    constexpr int NG = (JHI + 1) * 2;
+    constexpr int NG = (JHI + 1) * GPS32;
     uint2 W[2][GROUP32];
     load_tw32<LOGN, B, JHI, true, 0>(W[0], tw, twr, tmul, thi);
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        constexpr int j = JHI - g / 2;
+        constexpr int j = JHI - g / GPS32;
         if constexpr (g + 1 < NG) load_tw32<LOGN, B, JHI, true, g + 1>(W[(g + 1) % 2], tw, twr, tmul, thi);
         __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP32>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            constexpr int r0 = low_reg(j, (g % 2) * GROUP32 + k), r1 = r0 | (1 << j);
+            constexpr int r0 = low_reg(j, (g % GPS32) * GROUP32 + k), r1 = r0 | (1 << j);
             const uint2 w = W[g % 2][k];
             const u32 X = min_u32(v[r0], v[r0] - twoq);
             const u32 T = shoup32(v[r1], w.x, w.y, q);
@@ -394,7 +397,7 @@ __device__ __forceinline__ void gs_round32(u32 (&v)[32], const uint2* __restrict
 {
     const u32 twoq = 2 * q;
     const unsigned thi = t >> B;
-    constexpr int NG = (5 - JLO) * 2;
+    constexpr int NG = (5 - JLO) * GPS32;
     uint2 W[2][GROUP32];
     if (first) {
         static_for<GROUP32>([&](auto kc) { W[0][decltype(kc)::value] = (*first)[decltype(kc)::value]; });
@@ -403,7 +406,7 @@ __device__ __forceinline__ void gs_round32(u32 (&v)[32], const uint2* __restrict
     }
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        constexpr int j = JLO + g / 2;
+        constexpr int j = JLO + g / GPS32;
         constexpr int beta = B + j;
         constexpr bool last = (beta == LOGN - 1);
         if constexpr (g + 1 < NG) load_tw32<LOGN, B, JLO, false, g + 1>(W[(g + 1) % 2], tw, twr, tmul, thi);
@@ -414,7 +417,7 @@ __device__ __forceinline__ void gs_round32(u32 (&v)[32], const uint2* __restrict
         }
         static_for<GROUP32>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            constexpr int r0 = low_reg(j, (g % 2) * GROUP32 + k), r1 = r0 | (1 << j);
+            constexpr int r0 = low_reg(j, (g % GPS32) * GROUP32 + k), r1 = r0 | (1 << j);
             const u32 X = v[r0], Y = v[r1];
             u32 S = X + Y;
             S = min_u32(S, S - twoq);
@@ -479,6 +482,8 @@ __device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufR
 // One workgroup of 2^LOGN / 32 threads per polynomial of 2^LOGN words, persistent over the batch.  split: the polynomials
 // are the halves of 2^(LOGN+1)-word polynomials whose first (forward) / last (inverse) stage runs as a stage launch.
 template <int LOGN, bool FWD>
+// (two workgroups of 1024 threads per CU would need 64 VGPRs per thread; without the prefetch set and with twiddle groups
+// of 4 the forward kernel still wants 98 -- measured with a waves-per-SIMD bound of 8 -- so n = 2^15 stays at one)
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)       // 128 VGPRs: four waves per SIMD, i.e. as many workgroups per CU as the LDS image admits
 k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned num, unsigned split)
 {
