@@ -663,6 +663,10 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     }
     Scratch30* sc = scratch_for(s);
     if (!sc) return hipErrorOutOfMemory;
+    // the scratch table belongs to the (device, stream) pair: one call's prepare -> transform -> fallback sequence must
+    // reach the stream as a unit even when several host threads share the stream
+    static std::mutex launch_mutex;
+    std::lock_guard<std::mutex> launch_lock(launch_mutex);
     const unsigned epoch = next_epoch();
     const unsigned split = n == 65536 ? 1u : 0u;
     k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_native, split, FWD ? 1u : 0u, sc, epoch);
