@@ -297,3 +297,24 @@ def test_polymul_batch_shared_rejects_bad_groups(native, gpu):
     with pytest.raises(native.NTTError):
         ctx.polymul_batch_shared(a, a, 8, 4, 6)          # group not a multiple of division
     ctx.close()
+
+
+def test_empty_batches_are_no_ops(native, gpu):
+    """num = 0 / count = 0 on the round-2 entry points: accepted, nothing launched, nothing touched"""
+    import torch
+    from ntt_cuda_amd import bfv
+    n = 4096
+    qs = P.Q60[:3]
+    psis = [pow(psi, 32768 // n, q) for psi, q in zip(P.PSI60, qs)]
+    ctx = native.NTTContext(n, qs, psis)
+    a = torch.full((3, n), 5, dtype=torch.int64, device=gpu)
+    ctx.polymul_batch_shared(a, a, 0, 3, 0)
+    b = bfv.BFVContext(n, qs, psis, 1024, P.GAMMA61)
+    c = torch.full((2 * 3, n), 7, dtype=torch.int64, device=gpu)
+    L = native.lib()
+    assert L.mi355ntt_bfv_encrypt_batch(b._h, c.data_ptr(), c.data_ptr(), c.data_ptr(), c.data_ptr(), 0, None) == 0
+    assert L.mi355ntt_bfv_decrypt_batch(b._h, c.data_ptr(), c.data_ptr(), 0, None) == 0
+    torch.cuda.synchronize()
+    assert int(a.sum()) == 5 * 3 * n and int(c.sum()) == 7 * 6 * n
+    b.close()
+    ctx.close()
