@@ -11,6 +11,10 @@ namespace mi355ntt {
 
 // coalesced layout B0: register r of thread t holds coefficient (r << B0) | t; lane offset in a VGPR,
 // the r * (n/32) * 8 byte displacement in the buffer instruction's scalar offset
+// n = 2^11..2^14: layout 0 <-> memory through wave-local 16-byte row staging instead of a layout exchange + 8-byte accesses
+#ifndef MI355NTT_SMALL_ROW_STAGING
+#define MI355NTT_SMALL_ROW_STAGING 1
+#endif
 template <int LOGN>
 __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restrict__ poly, unsigned t)
 {
@@ -71,9 +75,17 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         forward_core<LOGN, HL, NEAR>(v, twp, t, p, lds);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMP(6);
+#if MI355NTT_SMALL_ROW_STAGING
+        // layout 0 (32 consecutive words per thread) leaves through the wave's own 8 KiB of the image with 16-byte stores
+        // (as on n = 2^15) instead of a workgroup-wide layout exchange and 8-byte stores
+        __syncthreads();        // every wave has read the last exchange: the image is free
+        wave_store_rows(v, lds + (t >> 6) * 1024u, make_rsrc(poly, G::N * 8u), (t >> 6) * 16384u, 0u);
+        MI355NTT_STAMP(7);
+#else
         exchange<LOGN, 0, G::B0>(v, lds, t);
         MI355NTT_STAMP(7);
         store_coalesced<LOGN>(v, poly, t);
+#endif
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
         MI355NTT_STAMP(8);
         __syncthreads();        // the next polynomial's first exchange reuses the LDS image
@@ -93,7 +105,12 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     u64 v[32];
     unsigned y = blockIdx.x;
     MI355NTT_STAMP(15);
+#if MI355NTT_SMALL_ROW_STAGING
+    // rows (16-byte loads) through the wave's own 8 KiB of the image straight into layout 0: no layout exchange
+    wave_load_rows(v, lds + (t >> 6) * 1024u, make_rsrc(a + (size_t)y * G::N, G::N * 8u), (t >> 6) * 16384u, 0u);
+#else
     load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+#endif
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -105,13 +122,21 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         const TwPair* twp = tw + (size_t)idx * G::N;
         u64* poly = a + (size_t)y * G::N;
         MI355NTT_STAMP(0);
+#if !MI355NTT_SMALL_ROW_STAGING
         exchange<LOGN, G::B0, 0>(v, lds, t);
+#endif
         MI355NTT_STAMP(1);
         inverse_core<LOGN, HL, NEAR>(v, twp, t, p, lds);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP(8);
         store_coalesced<LOGN>(v, poly, t);
+#if MI355NTT_SMALL_ROW_STAGING
+        __syncthreads();        // every wave has read the last exchange: the image is free for the row staging
+        if (y + gridDim.x < num)
+            wave_load_rows(v, lds + (t >> 6) * 1024u, make_rsrc(a + (size_t)(y + gridDim.x) * G::N, G::N * 8u), (t >> 6) * 16384u, 0u);
+#else
         if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+#endif
         MI355NTT_STAMP(9);
         __syncthreads();
     }
