@@ -69,6 +69,22 @@ inline int decryption_rns(const mi355ntt_bfv* bfv, unsigned long long* c, const 
     return mi355ntt_bfv_decrypt(bfv, c, secret_key, stream);
 }
 
+// ---- many ciphertexts per call (no counterpart in the reference, which encrypts one ciphertext per launch sequence): the
+// batch is laid out [2][count][q_amount + 1][n] -- all first components, then all second components; e likewise, m_polys
+// [count][n]; the secret key must hold all q_amount + 1 polynomials.  Each ciphertext receives the words the single drivers
+// above leave for it; plaintext of ciphertext z at c + (z (q_amount + 1) + q_amount - 1) n. ----
+inline int encryption_rns_batch(const mi355ntt_bfv* bfv, unsigned long long* c, const unsigned long long* public_key,
+                                const unsigned long long* e, const unsigned long long* m_polys_device, unsigned count, mi355ntt_stream stream)
+{
+    return mi355ntt_bfv_encrypt_batch(bfv, c, public_key, e, m_polys_device, count, stream);
+}
+
+inline int decryption_rns_batch(const mi355ntt_bfv* bfv, unsigned long long* c, const unsigned long long* secret_key, unsigned count,
+                                mi355ntt_stream stream)
+{
+    return mi355ntt_bfv_decrypt_batch(bfv, c, secret_key, count, stream);
+}
+
 // ---- the complete drivers, samplers included: `in` is the caller's random-byte buffer as in the reference
 // (mi355ntt_bfv_keygen_random_bytes / _encrypt_random_bytes give the sizes the drivers consume); `nonce` = 0 reproduces
 // the reference's fixed keystream (generate_random_default) ----
