@@ -78,6 +78,49 @@ int main(int argc, char** argv)
     printf("n = %u, %u primes (log q = %u): keygen %.1f us, encryption %.1f us, decryption %.1f us\n", n, primes,
            54 + 55 * (primes - 1), keygen * 1e3f, enc * 1e3f, dec * 1e3f);
     printf(correct ? "Decryption is correct\n" : "Decryption is WRONG\n");
+
+    // ---- many ciphertexts per call (argv[2] = count): sampled per ciphertext as above, laid out [2][count][primes][n],
+    // encrypted and decrypted with one call each; every message must come back ----
+    const unsigned count = argc > 2 ? (unsigned)atoi(argv[2]) : 0;
+    if (correct && count > 0) {
+        unsigned long long *cb, *eb, *mb;
+        const size_t half = poly * primes;                                              // one component of one ciphertext
+        HIPCK(hipMalloc(&cb, 2 * half * count));
+        HIPCK(hipMalloc(&eb, 2 * half * count));
+        HIPCK(hipMalloc(&mb, poly * count));
+        std::vector<unsigned long long> msgs((size_t)n * count);
+        for (size_t i = 0; i < msgs.size(); i++) msgs[i] = (i * 40503u + (i >> 7)) % t;
+        HIPCK(hipMemcpy(mb, msgs.data(), poly * count, hipMemcpyHostToDevice));
+        const unsigned char key[32] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+        for (unsigned z = 0; z < count; z++) {                                          // fresh keystream -> u | u and e0 | e1 of ciphertext z
+            RC(mi355ntt_salsa20_keystream(in, mi355ntt_bfv_encrypt_random_bytes(bfv), key, 100 + z, nullptr));
+            RC(mi355ntt_bfv_sample_encrypt(bfv, in, c, e, nullptr));
+            for (int h = 0; h < 2; h++) {
+                HIPCK(hipMemcpyAsync((char*)cb + (h * (size_t)count + z) * half, (char*)c + h * half, half, hipMemcpyDeviceToDevice, nullptr));
+                HIPCK(hipMemcpyAsync((char*)eb + (h * (size_t)count + z) * half, (char*)e + h * half, half, hipMemcpyDeviceToDevice, nullptr));
+            }
+        }
+        float encb = 0, decb = 0;
+        HIPCK(hipEventRecord(start));
+        RC(encryption_rns_batch(bfv, cb, public_key, eb, mb, count, nullptr));
+        HIPCK(hipEventRecord(stop));
+        HIPCK(hipEventSynchronize(stop));
+        HIPCK(hipEventElapsedTime(&encb, start, stop));
+        HIPCK(hipEventRecord(start));
+        RC(decryption_rns_batch(bfv, cb, secret_key, count, nullptr));
+        HIPCK(hipEventRecord(stop));
+        HIPCK(hipEventSynchronize(stop));
+        HIPCK(hipEventElapsedTime(&decb, start, stop));
+        std::vector<unsigned long long> back(n);
+        for (unsigned z = 0; z < count && correct; z++) {
+            HIPCK(hipMemcpy(back.data(), cb + ((size_t)z * primes + primes - 2) * n, poly, hipMemcpyDeviceToHost));
+            for (unsigned i = 0; i < n; i++)
+                if (back[i] != msgs[(size_t)z * n + i]) { correct = false; break; }
+        }
+        printf("%u ciphertexts per call: encryption %.1f us, decryption %.1f us (%.2f / %.2f us per ciphertext)\n", count, encb * 1e3f,
+               decb * 1e3f, encb * 1e3f / count, decb * 1e3f / count);
+        printf(correct ? "Batched decryption is correct\n" : "Batched decryption is WRONG\n");
+    }
     mi355ntt_bfv_destroy(bfv);
     return correct ? 0 : 1;
 }

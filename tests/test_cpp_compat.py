@@ -58,3 +58,11 @@ def test_bfv_demo_runs_like_the_reference_demo(native, gpu, primes):
     r = subprocess.run([build_demo(native), str(primes)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Decryption is correct" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bfv_demo_batched_drivers(native, gpu):
+    """the same program with 24 ciphertexts per call through compat/bfv_launch.hpp's encryption_rns_batch / decryption_rns_batch"""
+    r = subprocess.run([build_demo(native), "5", "24"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Decryption is correct" in r.stdout and "Batched decryption is correct" in r.stdout
