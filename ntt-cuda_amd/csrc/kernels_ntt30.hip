@@ -324,6 +324,19 @@ __device__ __forceinline__ void rows_to_layout0_32(u32 (&v)[32], u32* img, unsig
 #define NTT30_GROUP 8
 #endif
 constexpr int GROUP32 = NTT30_GROUP, GPS32 = 16 / GROUP32;      // butterflies per twiddle group, groups per stage
+
+// n = 2^15: the twiddles of the middle round (register field at bit 5: stage blocks 32 ... 512, 992 pairs = 8 KiB, two
+// distinct addresses per wave) stay in LDS for the life of the persistent workgroup -- one modulus per call, so every
+// polynomial of the workgroup uses the same ones.  That takes half of the vector twiddle loads off the vector-memory
+// counter: the middle round then never waits behind the prefetch of the next polynomial (results return in order).
+#ifndef NTT30_LDS_TW
+#define NTT30_LDS_TW 1
+#endif
+__device__ __forceinline__ uint2* tw2_lds()
+{
+    __shared__ uint2 buf[1024];
+    return buf;
+}
 template <int LOGN, int B, int JA, bool FWD, int G>
 __device__ __forceinline__ void load_tw32(uint2 (&W)[GROUP32], const uint2* __restrict__ tw, BufRsrc twr, unsigned tmul, unsigned thi)
 {
@@ -337,6 +350,12 @@ __device__ __forceinline__ void load_tw32(uint2 (&W)[GROUP32], const uint2* __re
         static_for<GROUP32>([&](auto kc) {
             constexpr int r0 = low_reg(j, (G % GPS32) * GROUP32 + decltype(kc)::value);
             W[decltype(kc)::value] = tw[len * tmul + ((unsigned)r0 >> (j + 1))];
+        });
+    } else if constexpr (NTT30_LDS_TW && LOGN == 15 && B == 5) {      // the workgroup's LDS copy (k_ntt30x fills it once): index as in the table, tmul folded in
+        const uint2* lt = tw2_lds() + len + (thi << (4 - j));
+        static_for<GROUP32>([&](auto kc) {
+            constexpr int r0 = low_reg(j, (G % GPS32) * GROUP32 + decltype(kc)::value);
+            W[decltype(kc)::value] = lt[(unsigned)r0 >> (j + 1)];
         });
     } else if constexpr (B == 0) {                       // per-thread twiddles, stored transposed by k_ntt30_prepare: entry k of thread t at k T + t
         const unsigned voff = thi * 8u;
@@ -522,6 +541,13 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
         for (unsigned i = 0; i < ((blockIdx.x >> 3) & 7u) * NTT30_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
 #endif
     if (blockIdx.x >= num) return;
+    if constexpr (NTT30_LDS_TW && LOGN == 15) {          // middle-round twiddles into LDS (read only after the first exchange's barriers)
+        const unsigned tm = split ? 2u + (blockIdx.x & 1u) : 1u;
+        for (unsigned i = 32u + t; i < 1024u; i += G::T) {
+            const unsigned l0 = 1u << (31u - __clz(i));
+            tw2_lds()[i] = tw[l0 * tm + (i - l0)];
+        }
+    }
     // inverse: the first twiddle group of the first round stays in registers (every polynomial of this workgroup belongs to
     // the same half when the transform is split: the grid is even whenever a workgroup sees more than one polynomial)
     [[maybe_unused]] uint2 W0[GROUP32];
