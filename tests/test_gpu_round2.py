@@ -318,3 +318,33 @@ def test_empty_batches_are_no_ops(native, gpu):
     assert int(a.sum()) == 5 * 3 * n and int(c.sum()) == 7 * 6 * n
     b.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("primes,num", [(3, 600), (5, 777)])
+def test_persistent_walk_with_modulus_count_not_dividing_the_grid(native, oracle, gpu, primes, num):
+    """n = 2^15 with more polynomials than workgroups and a prime count that does not divide the grid (256): the persistent
+    kernels carry the modulus index incrementally (forward walking up, inverse walking DOWN): every word of a ragged batch
+    against the oracle, forward, inverse and fused product."""
+    n = 32768
+    qs = (P.Q60 + [P.Q60_SPECIAL])[:primes]
+    psis = (P.PSI60 + [P.PSI60_SPECIAL])[:primes]
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = oracle.synth_batch(n, num, qs, 5)
+    A = oracle.forward_batch(a, prm, threads=THREADS)
+    d = dev(native, a)
+    ctx.forward_batch(d, num)
+    assert sha(host(native, d)) == sha(A)
+    ctx.inverse_batch(d, num)
+    assert np.array_equal(host(native, d), a)
+    b = oracle.synth_batch(n, num, qs, 6)
+    B = oracle.forward_batch(b, prm, threads=THREADS)
+    want = oracle.inverse_batch(oracle.pointwise_batch(A, B, prm), prm, threads=THREADS)
+    d_b = dev(native, B)
+    ctx.polymul_batch(d, d_b, num)
+    assert sha(host(native, d)) == sha(want)
+    # inverse alone on NTT-domain data that is not a forward image of anything special
+    d2 = dev(native, B)
+    ctx.inverse_batch(d2, num)
+    assert sha(host(native, d2)) == sha(oracle.inverse_batch(B, prm, threads=THREADS))
+    ctx.close()
