@@ -348,3 +348,25 @@ def test_persistent_walk_with_modulus_count_not_dividing_the_grid(native, oracle
     ctx.inverse_batch(d2, num)
     assert sha(host(native, d2)) == sha(oracle.inverse_batch(B, prm, threads=THREADS))
     ctx.close()
+
+
+@pytest.mark.parametrize("n,num", [(2048, 9001), (4096, 5003), (8192, 2101), (16384, 701)])
+def test_small_ring_sizes_walk_more_polynomials_than_workgroups(native, oracle, gpu, n, num):
+    """n = 2^11..2^14: batches larger than the resident grid (every workgroup walks several polynomials; the rows enter and
+    leave through the wave-local staging with the next polynomial's loads behind the stores): whole-batch digests against
+    the oracle for forward, inverse and the fused product, 3 primes (does not divide the grid)."""
+    qs = P.Q60[:3]
+    psis = [pow(psi, 32768 // n, q) for psi, q in zip(P.PSI60, qs)]
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = oracle.synth_batch(n, num, qs, 9)
+    A = oracle.forward_batch(a, prm, threads=THREADS)
+    d = dev(native, a)
+    ctx.forward_batch(d, num)
+    assert sha(host(native, d)) == sha(A)
+    ctx.inverse_batch(d, num)
+    assert np.array_equal(host(native, d), a)
+    d_b = dev(native, A)
+    ctx.polymul_batch(d, d_b, num)
+    assert sha(host(native, d)) == sha(oracle.inverse_batch(oracle.pointwise_batch(A, A, prm), prm, threads=THREADS))
+    ctx.close()
