@@ -119,3 +119,27 @@ def test_30bit_entry_points_reject_bad_arguments(native):
     assert L.mi355ntt_forward30_raw(None, 2048, None, 12931073, 21767333, 24, None) == native.EINVAL
     assert L.mi355ntt_forward30_batch_raw(native.vp(16), 1000, native.vp(16), 1, 12931073, 21767333, 24, None) == native.EUNSUPPORTED
     assert L.mi355ntt_barrett30_raw(native.vp(16), native.vp(16), 8, 1 << 31, 5, 31, None) == native.EUNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,num", [(32768, 601), (4096, 2500), (65536, 301), (2048, 4500)])
+def test_gpu_30bit_persistent_loop_matches_oracle(native, oracle, gpu, n, num):
+    """more polynomials than resident workgroups: every workgroup of the native kernels walks several polynomials (prefetch
+    of the next one in a second register set, zero-length prefetch past the end, middle-round twiddles resident in LDS at
+    n = 2^15); every word of forward and inverse against the oracle"""
+    import torch
+    q, psi, _, _, bits = PARAMS30[n]
+    prm = oracle.Params30(n, q, psi)
+    rng = np.random.default_rng(11 * n)
+    a = rng.integers(0, q, size=(num, n), dtype=np.uint32)
+    dev32 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(gpu)
+    host32 = lambda t: t.cpu().numpy().view(np.uint32)
+    d_a = dev32(a)
+    d_psi, d_psiinv = dev32(prm.psi_tab), dev32(prm.psiinv_tab)
+    native.forward30(d_a, n, q, prm.mu, bits, d_psi, num)
+    torch.cuda.synchronize()
+    A = oracle.forward30(a, prm)
+    assert np.array_equal(host32(d_a), A)
+    native.inverse30(d_a, n, q, prm.mu, bits, d_psiinv, num)
+    torch.cuda.synchronize()
+    assert np.array_equal(host32(d_a), a)
