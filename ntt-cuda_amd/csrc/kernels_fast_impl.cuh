@@ -28,7 +28,7 @@ __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restri
     for (int r = 0; r < 32; r++) v[r] = buf_load_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u);
 }
 
-template <int LOGN>
+template <int LOGN, int AUX = MI355NTT_STREAM_AUX_ST>
 __device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restrict__ poly, unsigned t)
 {
 #ifdef MI355NTT_ABLATE_GLOBAL
@@ -40,7 +40,12 @@ __device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restr
 #endif
     const BufRsrc rs = make_rsrc(poly, Geo<LOGN>::N * 8u);
 #pragma unroll
-    for (int r = 0; r < 32; r++) buf_store_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u, v[r]);
+    for (int r = 0; r < 32; r++) {
+        v2u32 x;
+        x.x = lo32(v[r]);
+        x.y = hi32(v[r]);
+        __builtin_amdgcn_raw_buffer_store_b64(x, rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u, AUX);
+    }
 }
 
 // Persistent workgroups: grid = min(num, resident workgroups); each workgroup walks polynomials
@@ -217,6 +222,15 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
         for (unsigned i = 0; i < n; i++) __builtin_amdgcn_s_sleep(32);
     }
 }
+// Cache policy of k_inverse15's stores (aux bits: 1 = sc0, 16 = sc1; 17 = write-through at system scope).  Written through,
+// the L2s hold no dirty lines when the kernel ends: the idle gap to the next launch shrinks from 12.1 to 8.7 us (launch log
+// of the stamped build) and the kernel alone runs 2 % faster in tools/kbench (0.1743-0.1756 -> 0.1694-0.1718 ms per 1024
+// transforms) -- but forward -> inverse pairs do not move (0.3254-0.3294 vs 0.3220-0.3294 ms) and whatever reads the result next
+// finds it in the memory-side cache instead of the L2, so the default policy stays
+// (profiles/r02_walk_order_and_store_policy.txt, L).
+#ifndef MI355NTT_INV15_AUX_ST
+#define MI355NTT_INV15_AUX_ST MI355NTT_STREAM_AUX_ST
+#endif
 // Order in which k_inverse15's persistent workgroups walk the batch: 1 = from the last polynomial down.  A forward
 // transform is normally followed by an inverse over the same polynomials (and the other way round): walking them in
 // opposite directions makes each kernel start on what the previous one wrote last, i.e. on what is still in the
@@ -354,7 +368,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP2(it, 5);
-        store_coalesced<LOGN>(v, poly, t);
+        store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, t);
         if (y + gridDim.x < num)
             wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y + gridDim.x)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u),
                            0u, lane);
