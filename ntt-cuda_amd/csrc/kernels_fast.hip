@@ -94,6 +94,11 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         d.near_sh = pp.k > 32 ? pp.k - 32 : 0;
         d.near_mask = pp.k > 32 ? (u32)((1ull << (pp.k - 32)) - 1) : 0;
         d.pad_ = 0;
+        d.twn[0] = TwPair{pp.ninv, shoup(pp.ninv, pp.q)};
+        for (unsigned j = 1; j < 32; j++) {                   // (n >= 2048: the entries exist)
+            const u64 w = mulmod(h_psiinv[(size_t)i * n + j], pp.ninv, pp.q);
+            d.twn[j] = TwPair{w, shoup(w, pp.q)};
+        }
         if (!near_ok) all_near = false;
     }
     if (all_near) t->hl |= 16;

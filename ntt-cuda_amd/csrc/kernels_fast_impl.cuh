@@ -15,7 +15,13 @@ namespace mi355ntt {
 #ifndef MI355NTT_SMALL_ROW_STAGING
 #define MI355NTT_SMALL_ROW_STAGING 1
 #endif
-template <int LOGN>
+// PAIR16: issue order (0, 16, 1, 17, ...) -- the order in which a forward round on register bits 4..0 consumes the
+// registers (its first stage pairs r with r + 16; loads return in order, so the first butterfly can start after two loads
+// have landed instead of seventeen)
+#ifndef MI355NTT_FWD_LOAD_PAIR16
+#define MI355NTT_FWD_LOAD_PAIR16 0
+#endif
+template <int LOGN, bool PAIR16 = false>
 __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restrict__ poly, unsigned t)
 {
 #ifdef MI355NTT_ABLATE_GLOBAL
@@ -24,8 +30,12 @@ __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restri
     return;
 #endif
     const BufRsrc rs = make_rsrc(poly, Geo<LOGN>::N * 8u);
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = buf_load_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u);
+    static_for<32>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int r = PAIR16 ? ((i >> 1) | ((i & 1) << 4)) : i;
+        v[r] = buf_load_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u);
+        if constexpr (PAIR16) __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise re-sorts the loads by register)
+    });
 }
 
 template <int LOGN, int AUX = MI355NTT_STREAM_AUX_ST>
@@ -244,6 +254,36 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 #define MI355NTT_POLY_SLOT(y) (y)
 #endif
 
+// Experiment (round 3): polynomial tickets.  Instead of walking y, y + grid, ... every workgroup draws its next polynomial
+// from a counter (one atomicAdd per polynomial by its first lane, handed to the other waves through an LDS slot that is read
+// behind the exchange barrier): a workgroup that runs faster transforms more polynomials.
+#ifndef MI355NTT_TICKETS
+#define MI355NTT_TICKETS 0
+#endif
+#if MI355NTT_TICKETS
+__device__ unsigned g_tickets[8];      // [0] next ticket, [1] workgroups that have left (forward); [4], [5] inverse
+struct Ticket {
+    unsigned y, ymod;
+};
+// first lane of the workgroup: draw the next polynomial and leave it in the slot
+__device__ __forceinline__ void ticket_draw(unsigned* ctr, volatile unsigned* slot, unsigned division, unsigned num_if_descending = 0)
+{
+    if (threadIdx.x == 0) {
+        const unsigned yn = gridDim.x + atomicAdd(ctr, 1u);
+        slot[0] = yn;
+        slot[1] = num_if_descending ? (yn < num_if_descending ? (num_if_descending - 1u - yn) % division : 0u) : yn % division;
+    }
+}
+// the workgroup whose exit is the last one resets the counters for the next launch
+__device__ __forceinline__ void ticket_leave(unsigned* ctr)
+{
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ctr + 1, 1u) == gridDim.x - 1) { ctr[0] = 0; ctr[1] = 0; __threadfence(); }
+    }
+}
+#endif
+
 // ================================================================================================
 // n = 2^15: one workgroup-wide exchange per transform, everything else wave-local (ntt_core.cuh).
 // forward : load(layout 10) R1 | sync, exchange 10->5 | R2 | wave transpose 5->0 | R3 | canon | wave-local row store
@@ -258,6 +298,9 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+#if MI355NTT_TICKETS
+    __shared__ unsigned tslot[4];
+#endif
     // Thread-derived values are rebuilt where they are used -- the wave index lives in an SGPR, the lane index comes from
     // v_mbcnt -- instead of surviving the polynomial loop in VGPRs the kernel does not have (they were its spills, reloaded
     // from scratch in front of the exchange and of the row store).
@@ -269,7 +312,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_FWD, MI355NTT_STAGGER_FWD_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
-    load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, fresh_t());
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, fresh_t());
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
@@ -277,7 +320,14 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
     unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+#if MI355NTT_TICKETS
+    for (; y < num;) {
+        ticket_draw(g_tickets, tslot + 2 * (it & 1), division);
+        unsigned ynext;
+#else
     for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
+        const unsigned ynext = y + gridDim.x;
+#endif
         const unsigned idx = prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
@@ -294,6 +344,10 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
         MI355NTT_STAMPV(2, -1);
         exchange<LOGN, 10, 5>(v, lds, fresh_t());
+#if MI355NTT_TICKETS
+        ynext = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1)]);
+        const unsigned ymod_next = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1) + 1]);
+#endif
         MI355NTT_STAMPV(3, 3);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
         ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, fresh_t(), p);
@@ -306,11 +360,18 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic instead of a VGPR kept live across the loop)
         wave_store_rows(v, lds + wave_s * WAVE_SLICE_WORDS, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
         MI355NTT_STAMPV(-1, 5);
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)MI355NTT_POLY_SLOT(y + gridDim.x) * G::N, fresh_t());
+        if (ynext < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N, fresh_t());
         MI355NTT_STAMPV(6, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
+#if MI355NTT_TICKETS
+        y = ynext;
+        ymod = ymod_next;
+#endif
     }
+#if MI355NTT_TICKETS
+    ticket_leave(g_tickets);
+#endif
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }
@@ -324,6 +385,9 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+#if MI355NTT_TICKETS
+    __shared__ unsigned tslot[4];
+#endif
     const unsigned t0 = threadIdx.x;
     const unsigned lane = t0 & 63u, wave = t0 >> 6;
     u64* slice = lds + wave * WAVE_SLICE_WORDS;
@@ -342,7 +406,14 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     unsigned ymod = __builtin_amdgcn_readfirstlane(MI355NTT_INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
     if (MI355NTT_INV_DESCENDING && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+#if MI355NTT_TICKETS
+    for (; y < num;) {
+        ticket_draw(g_tickets + 4, tslot + 2 * (it & 1), division, MI355NTT_INV_DESCENDING ? num : 0u);
+        unsigned ynext;
+#else
     for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
+        const unsigned ynext = y + gridDim.x;
+#endif
         unsigned t = t0;
         asm volatile("" : "+v"(t));      // thread-derived offsets are recomputed per polynomial, not kept live across the loop
         const unsigned lane = t & 63u, wave = t >> 6;
@@ -363,19 +434,30 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         __syncthreads();                                  // private slices are idle from here on
         MI355NTT_STAMP2(it, 3);
         exchange<LOGN, 5, 10>(v, lds, t);
+#if MI355NTT_TICKETS
+        ynext = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1)]);
+        const unsigned ymod_next = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1) + 1]);
+#endif
         MI355NTT_STAMP2(it, 4);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
         gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, t, p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP2(it, 5);
         store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, t);
-        if (y + gridDim.x < num)
-            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y + gridDim.x)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u),
+        if (ynext < num)
+            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u),
                            0u, lane);
         MI355NTT_STAMP2(it, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
+#if MI355NTT_TICKETS
+        y = ynext;
+        ymod = ymod_next;
+#endif
     }
+#if MI355NTT_TICKETS
+    ticket_leave(g_tickets + 4);
+#endif
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }

@@ -89,6 +89,10 @@ constexpr unsigned kWgLogCap = 1u << 16;
 #define MI355NTT_STAMP_FLUSH
 #endif
 
+struct TwPair {       // {w, floor(w * 2^64 / q)}
+    u64 w, wp;
+};
+
 // Per-prime constants, read with scalar loads (replaces __constant__ q_cons/mu_cons/q_bit_cons).
 struct PrimeDev {
     u64 q, nq;        // modulus and 2^64 - q
@@ -103,6 +107,9 @@ struct PrimeDev {
     u32 near_sh;      // k - 32
     u32 near_mask;    // 2^(k-32) - 1
     u32 pad_;
+    // n^-1 folded into the LAST inverse round (gs_round, SCALE): twn[0] = {n^-1, companion}, twn[i] = psi^-bitrev(i) * n^-1
+    // for i = 1..31 -- the twiddles of the top five GS stages (reference table entries [1, 32)) times n^-1.
+    TwPair twn[32];
 };
 
 // Checked raw calls (kernels.hpp, kGuardBit): the record in front of the PrimeDev array holds {current epoch, epoch of the
@@ -114,10 +121,6 @@ __device__ __forceinline__ bool guard_says_skip(const PrimeDev* primes, unsigned
     const unsigned* g = reinterpret_cast<const unsigned*>(primes - 1);
     return g[0] == g[1];
 }
-
-struct TwPair {       // {w, floor(w * 2^64 / q)}
-    u64 w, wp;
-};
 
 // Device twiddle layout.  The reference table keeps stage `len` in entries [len, 2 len) indexed by the
 // butterfly group p = i >> (bit + 1).  A thread of a round whose register field sits at bit B needs, for the
@@ -670,8 +673,11 @@ struct Ring {
 
 // Twiddles of butterfly group G of a round (GROUP butterflies per group, 16 / GROUP groups per stage).
 // FWD: stages run j = JA, JA-1, ...; INV: j = JA, JA+1, ...
-template <int LOGN, int B, int JA, bool FWD, int GROUP, int G>
-__device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* __restrict__ tw, BufRsrc twr, unsigned thi)
+// SCALE (inverse, last round only): the butterflies whose register bits JA .. j-1 are all zero have not met a twiddle in this
+// round yet -- they take theirs from p.twn, i.e. times n^-1 (see gs_round).
+__host__ __device__ constexpr bool zero_history(int r0, int j, int jlo) { return ((r0 & ((1 << j) - 1)) >> jlo) == 0; }
+template <int LOGN, int B, int JA, bool FWD, int GROUP, int G, bool SCALE = false>
+__device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* __restrict__ tw, BufRsrc twr, unsigned thi, const PrimeDev& p)
 {
     constexpr int GPS = 16 / GROUP;                         // groups per stage
     constexpr int j = FWD ? JA - G / GPS : JA + G / GPS;
@@ -684,9 +690,10 @@ __device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* 
 #ifdef MI355NTT_ABLATE_TWIDDLE
         W[k].w = 0x123456789abcdefULL + r0; W[k].wp = 0xfedcba987654321ULL + j; (void)tw; (void)twr; (void)thi;
 #else
-        if constexpr (B == Geo<LOGN>::B0)                   // group index independent of the thread: scalar load
-            W[k] = tw[len + u];
-        else
+        if constexpr (B == Geo<LOGN>::B0) {                 // group index independent of the thread: scalar load
+            if constexpr (SCALE && !FWD && zero_history(r0, j, JA)) W[k] = p.twn[len + u];
+            else W[k] = tw[len + u];
+        } else
 #ifdef MI355NTT_ABLATE_TWL1     // timing experiment: same loads, every address inside one 4 KiB window (always L1 hits)
             W[k] = buf_load_tw(twr, (thi * 16u) & 0xff0u, (tw_dev_index(LOGN, B, j, len, 0, u) * 16u) & 0xff0u);
 #else
@@ -728,7 +735,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
     TwPair W[DEPTH][GROUP];
     static_for<DEPTH - 1>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
-        if constexpr (d < NG) load_tw_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi);
+        if constexpr (d < NG) load_tw_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi, p);
     });
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -737,7 +744,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
         constexpr bool red = (RMASK >> s) & 1u;
         TwPair (&Wc)[GROUP] = W[g % DEPTH];
         prio_hook<PSPLIT, PAFTER, g>(t);
-        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
+        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, p);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -774,11 +781,17 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
     constexpr bool EX = Lazy<HL>::EXACT;
     constexpr int GROUP = Ring<LOGN, B>::GROUP, DEPTH = Ring<LOGN, B>::DEPTH, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
     constexpr bool VEC = (B != Geo<LOGN>::B0);
+    // The scaling by n^-1 (the reference halves in every stage, ntt_60bit.cuh:132,166,178) is folded into the twiddles of the
+    // LAST round: in stage j the butterflies whose register bits JLO .. j-1 are zero hold values that have only been summed in
+    // this round so far; their difference output takes twiddle * n^-1 (p.twn), every later butterfly of that output uses the
+    // plain table.  What has been summed in all stages -- the registers below 2^JLO -- is multiplied by n^-1 in the last stage:
+    // 2^JLO products per thread instead of 16.
+    constexpr bool SCALE = !VEC;
     const unsigned thi = t >> B;
     TwPair W[DEPTH][GROUP];
     static_for<DEPTH - 1>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
-        if constexpr (d < NG) load_tw_group<LOGN, B, JLO, false, GROUP, d>(W[d], tw, twr, thi);
+        if constexpr (d < NG) load_tw_group<LOGN, B, JLO, false, GROUP, d, SCALE>(W[d], tw, twr, thi, p);
     });
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -789,7 +802,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
         const u64 cq = (u64)POL.cmul[beta] * p.q;
         TwPair (&Wc)[GROUP] = W[g % DEPTH];
         prio_hook<PSPLIT, PAFTER, g>(t);
-        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
+        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1, SCALE>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, p);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -798,21 +811,18 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
             const u64 X = v[r0], Y = v[r1];
             u64 S = X + Y;
             const u64 D = X + cq - Y;
-            if constexpr (last) {
-                // length = 1: single twiddle, n^-1 folded into both outputs (the reference halves every stage)
-                if constexpr (!EX && MI355NTT_MAD_CHAIN) {
-                    v[r0] = mul_shoup4m<true>(S, p.ninv, p.ninv_p, p.nq);
-                    v[r1] = mul_shoup4m<true>(D, p.w1n, p.w1n_p, p.nq);
-                } else {
-                    v[r0] = mul_shoup<EX>(S, p.ninv, p.ninv_p, p.nq);
-                    v[r1] = mul_shoup<EX>(D, p.w1n, p.w1n_p, p.nq);
-                }
+            // values entering canon_after_inverse: any multiple range for NEAR (it folds), below TQ*q otherwise
+            constexpr bool fin_red = last && !(NEAR && !EX) && (2 * POL.cmul[beta] > Lazy<HL>::TQ);
+            if constexpr (last && zero_history(r0, 5, JLO)) {
+                // summed in every stage of this round: the only values that still need an explicit n^-1
+                if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r0] = mul_shoup4m<true>(S, p.twn[0].w, p.twn[0].wp, p.nq);
+                else v[r0] = mul_shoup<EX>(S, p.twn[0].w, p.twn[0].wp, p.nq);
             } else {
-                if constexpr (red) S = reduce_2q_sel<NEAR>(S, p);
+                if constexpr (red || fin_red) S = reduce_2q_sel<NEAR>(S, p);
                 v[r0] = S;
-                if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r1] = mul_shoup4m<!VEC>(D, Wc[k].w, Wc[k].wp, p.nq);
-                else v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
             }
+            if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r1] = mul_shoup4m<!VEC>(D, Wc[k].w, Wc[k].wp, p.nq);
+            else v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
     });
