@@ -19,7 +19,7 @@ namespace mi355ntt {
 // registers (its first stage pairs r with r + 16; loads return in order, so the first butterfly can start after two loads
 // have landed instead of seventeen)
 #ifndef MI355NTT_FWD_LOAD_PAIR16
-#define MI355NTT_FWD_LOAD_PAIR16 0
+#define MI355NTT_FWD_LOAD_PAIR16 1
 #endif
 template <int LOGN, bool PAIR16 = false>
 __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restrict__ poly, unsigned t)
@@ -75,7 +75,7 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     u64 v[32];
     unsigned y = blockIdx.x;
     MI355NTT_STAMP(15);
-    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)y * G::N, t);
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -101,7 +101,7 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         MI355NTT_STAMP(7);
         store_coalesced<LOGN>(v, poly, t);
 #endif
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        if (y + gridDim.x < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(y + gridDim.x) * G::N, t);
         MI355NTT_STAMP(8);
         __syncthreads();        // the next polynomial's first exchange reuses the LDS image
     }
@@ -141,7 +141,7 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         exchange<LOGN, G::B0, 0>(v, lds, t);
 #endif
         MI355NTT_STAMP(1);
-        inverse_core<LOGN, HL, NEAR>(v, twp, t, p, lds);
+        inverse_core<LOGN, HL, NEAR>(v, twp, t, p, lds, primes[idx].twn);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP(8);
         store_coalesced<LOGN>(v, poly, t);
@@ -254,36 +254,6 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 #define MI355NTT_POLY_SLOT(y) (y)
 #endif
 
-// Experiment (round 3): polynomial tickets.  Instead of walking y, y + grid, ... every workgroup draws its next polynomial
-// from a counter (one atomicAdd per polynomial by its first lane, handed to the other waves through an LDS slot that is read
-// behind the exchange barrier): a workgroup that runs faster transforms more polynomials.
-#ifndef MI355NTT_TICKETS
-#define MI355NTT_TICKETS 0
-#endif
-#if MI355NTT_TICKETS
-__device__ unsigned g_tickets[8];      // [0] next ticket, [1] workgroups that have left (forward); [4], [5] inverse
-struct Ticket {
-    unsigned y, ymod;
-};
-// first lane of the workgroup: draw the next polynomial and leave it in the slot
-__device__ __forceinline__ void ticket_draw(unsigned* ctr, volatile unsigned* slot, unsigned division, unsigned num_if_descending = 0)
-{
-    if (threadIdx.x == 0) {
-        const unsigned yn = gridDim.x + atomicAdd(ctr, 1u);
-        slot[0] = yn;
-        slot[1] = num_if_descending ? (yn < num_if_descending ? (num_if_descending - 1u - yn) % division : 0u) : yn % division;
-    }
-}
-// the workgroup whose exit is the last one resets the counters for the next launch
-__device__ __forceinline__ void ticket_leave(unsigned* ctr)
-{
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(ctr + 1, 1u) == gridDim.x - 1) { ctr[0] = 0; ctr[1] = 0; __threadfence(); }
-    }
-}
-#endif
-
 // ================================================================================================
 // n = 2^15: one workgroup-wide exchange per transform, everything else wave-local (ntt_core.cuh).
 // forward : load(layout 10) R1 | sync, exchange 10->5 | R2 | wave transpose 5->0 | R3 | canon | wave-local row store
@@ -298,9 +268,6 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-#if MI355NTT_TICKETS
-    __shared__ unsigned tslot[4];
-#endif
     // Thread-derived values are rebuilt where they are used -- the wave index lives in an SGPR, the lane index comes from
     // v_mbcnt -- instead of surviving the polynomial loop in VGPRs the kernel does not have (they were its spills, reloaded
     // from scratch in front of the exchange and of the row store).
@@ -320,14 +287,8 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
     unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
-#if MI355NTT_TICKETS
-    for (; y < num;) {
-        ticket_draw(g_tickets, tslot + 2 * (it & 1), division);
-        unsigned ynext;
-#else
     for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
         const unsigned ynext = y + gridDim.x;
-#endif
         const unsigned idx = prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
@@ -344,10 +305,6 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
         MI355NTT_STAMPV(2, -1);
         exchange<LOGN, 10, 5>(v, lds, fresh_t());
-#if MI355NTT_TICKETS
-        ynext = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1)]);
-        const unsigned ymod_next = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1) + 1]);
-#endif
         MI355NTT_STAMPV(3, 3);
         MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
         ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, fresh_t(), p);
@@ -364,14 +321,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         MI355NTT_STAMPV(6, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
-#if MI355NTT_TICKETS
-        y = ynext;
-        ymod = ymod_next;
-#endif
     }
-#if MI355NTT_TICKETS
-    ticket_leave(g_tickets);
-#endif
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }
@@ -385,19 +335,20 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-#if MI355NTT_TICKETS
-    __shared__ unsigned tslot[4];
-#endif
-    const unsigned t0 = threadIdx.x;
-    const unsigned lane = t0 & 63u, wave = t0 >> 6;
-    u64* slice = lds + wave * WAVE_SLICE_WORDS;
+    // thread-derived values are rebuilt where they are used (wave index in an SGPR, lane index from v_mbcnt), as in
+    // k_forward15: kept live across the polynomial loop they are spills in the general-prime instantiations
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+s"(wave_s));
+    auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
+    u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
     if (y >= num) return;
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
-    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u), 0u, lane);
+    // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic)
+    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
@@ -406,18 +357,8 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     unsigned ymod = __builtin_amdgcn_readfirstlane(MI355NTT_INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
     if (MI355NTT_INV_DESCENDING && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
-#if MI355NTT_TICKETS
-    for (; y < num;) {
-        ticket_draw(g_tickets + 4, tslot + 2 * (it & 1), division, MI355NTT_INV_DESCENDING ? num : 0u);
-        unsigned ynext;
-#else
     for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
         const unsigned ynext = y + gridDim.x;
-#endif
-        unsigned t = t0;
-        asm volatile("" : "+v"(t));      // thread-derived offsets are recomputed per polynomial, not kept live across the loop
-        const unsigned lane = t & 63u, wave = t >> 6;
-        u64* slice = lds + wave * WAVE_SLICE_WORDS;
         const unsigned idx = prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
@@ -425,39 +366,27 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         u64* poly = a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N;
         MI355NTT_STAMP2(it, 0);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
-        gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         MI355NTT_STAMP2(it, 1);
-        wave_transpose_0_to_5(v, slice, lane);
+        wave_transpose_0_to_5(v, slice, fresh_lane_id());
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-        gs_round<LOGN, HL, 5, 0, NEAR, MI355NTT_PSPLIT_I2, MI355NTT_PRIO_I2B>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 5, 0, NEAR, MI355NTT_PSPLIT_I2, MI355NTT_PRIO_I2B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         MI355NTT_STAMP2(it, 2);
         __syncthreads();                                  // private slices are idle from here on
         MI355NTT_STAMP2(it, 3);
-        exchange<LOGN, 5, 10>(v, lds, t);
-#if MI355NTT_TICKETS
-        ynext = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1)]);
-        const unsigned ymod_next = __builtin_amdgcn_readfirstlane(tslot[2 * (it & 1) + 1]);
-#endif
+        exchange<LOGN, 5, 10>(v, lds, fresh_t());
         MI355NTT_STAMP2(it, 4);
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, t, p);
+        gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP2(it, 5);
-        store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, t);
+        store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
         if (ynext < num)
-            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + __builtin_amdgcn_readfirstlane(wave) * 2048u, 16384u),
-                           0u, lane);
+            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
         MI355NTT_STAMP2(it, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
-#if MI355NTT_TICKETS
-        y = ynext;
-        ymod = ymod_next;
-#endif
     }
-#if MI355NTT_TICKETS
-    ticket_leave(g_tickets + 4);
-#endif
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }
@@ -498,7 +427,7 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     u64 v[32];
     unsigned y = blockIdx.x;
     stagger_start<MI355NTT_STAGGER_MUL>();
-    load_coalesced<LOGN>(v, a + (size_t)y * G::N, fresh_t());
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)y * G::N, fresh_t());
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -538,17 +467,17 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
             });
         }
         // ---- inverse ----
-        gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, fresh_t(), p);
+        gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         wave_transpose_0_to_5(v, slice, fresh_lane_id());
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-        gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, fresh_t(), p);
+        gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         __syncthreads();
         exchange<LOGN, 5, 10>(v, lds, fresh_t());
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, fresh_t(), p);
+        gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         store_coalesced<LOGN>(v, poly, fresh_t());
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, fresh_t());
+        if (y + gridDim.x < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(y + gridDim.x) * G::N, fresh_t());
     }
 }
 
@@ -574,7 +503,7 @@ k_fwd15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev*
     const TwPair* twp = tw + (size_t)idx * G::N;
     u64* poly = a + (size_t)y * G::N;
     u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly, t);
     ct_round<LOGN, HL, 10, 4, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p);
     store_coalesced<LOGN>(v, poly, t);
 }
@@ -624,9 +553,9 @@ k_inv15_rows(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev*
     const BufRsrc prs = make_rsrc(poly, G::N * 8u);
     u64 v[32];
     wave_load_rows(v, slice, prs, wave * 16384u, lane);
-    gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p);
+    gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p, primes[idx].twn);
     wave_transpose_0_to_5(v, slice, lane);
-    gs_round<LOGN, HL, 5, 0, NEAR>(v, twp, twr, t, p);
+    gs_round<LOGN, HL, 5, 0, NEAR>(v, twp, twr, t, p, primes[idx].twn);
     const unsigned voff = (((t >> 5) << 10) | (t & 31u)) * 8u;
     static_for<32>([&](auto rc) { buf_store_u64(prs, voff, (unsigned)decltype(rc)::value * 256u, v[decltype(rc)::value]); });
 }
@@ -646,7 +575,7 @@ k_inv15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev*
     u64* poly = a + (size_t)y * G::N;
     u64 v[32];
     load_coalesced<LOGN>(v, poly, t);
-    gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p);
+    gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p, primes[idx].twn);
     static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
     store_coalesced<LOGN>(v, poly, t);
 }
@@ -690,9 +619,9 @@ k_mul15_rows(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __
             v[16 + r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[16 + r], p), p.q), bb[r], p.q, p.mu, p.k);
         });
     }
-    gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, t, p);
+    gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, t, p, primes[idx].twn);
     wave_transpose_0_to_5(v, slice, lane);
-    gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, t, p);
+    gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, t, p, primes[idx].twn);
     static_for<32>([&](auto rc) { buf_store_u64(prs, voff, (unsigned)decltype(rc)::value * 256u, v[decltype(rc)::value]); });
 }
 
@@ -723,7 +652,7 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     const u64* bp = bhat + (size_t)sb.index(y, idx, division) * G::N;
     const unsigned t = threadIdx.x;
     u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly, t);
     forward_core<LOGN, HL, NEAR>(v, twf + (size_t)idx * G::N, t, p, lds);
     // layout 0: this thread holds NTT values 32t .. 32t+31; the inverse starts from the same layout
     const BufRsrc brs = make_rsrc(bp, G::N * 8u);
@@ -736,7 +665,7 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
         v[r + 1] = barrett_mul(x1, bb.wp, p.q, p.mu, p.k);
         if ((r & 6) == 6) __builtin_amdgcn_sched_barrier(0);
     }
-    inverse_core<LOGN, HL, NEAR>(v, twi + (size_t)idx * G::N, t, p, lds);
+    inverse_core<LOGN, HL, NEAR>(v, twi + (size_t)idx * G::N, t, p, lds, primes[idx].twn);
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL, NEAR>(v[r], p);
     store_coalesced<LOGN>(v, poly, t);

@@ -222,19 +222,25 @@ __device__ __forceinline__ u64 mad32_chain0(u32 a, u32 b)
     else asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
     return d;
 }
-// y*w + h*(2^64 - q) + base  (mod 2^64); without base: congruent to y*w and in [0, 4q).  nq is always scalar (PrimeDev).
+// y*w + h*(2^64 - q) + base  (mod 2^64) for a given quotient estimate h
 template <bool TWS>
-__device__ __forceinline__ u64 mul_shoup4m_acc(u64 y, u64 w, u64 wp, u64 nq, u64 base)
+__device__ __forceinline__ u64 shoup_rem_chain(u64 y, u64 w, u64 h, u64 nq, u64 base)
 {
-    const u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
-    const u32 w0 = lo32(w), w1 = hi32(w), n0 = lo32(nq), n1 = hi32(nq);
-    const u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w), n0 = lo32(nq), n1 = hi32(nq);
     const u32 h0 = lo32(h), h1 = hi32(h);
     const u64 acc = mad32(h0, n0, mad32(y0, w0, base));
     const u64 c = mad32_chain<true>(h1, n0, mad32_chain<true>(h0, n1, mad32_chain<TWS>(y1, w0, mad32_chain0<TWS>(y0, w1))));
     u32 xh = hi32(acc);
     asm("v_add_u32 %0, %0, %1" : "+v"(xh) : "v"(lo32(c)));     // (as C++ the compiler re-associates it into a 64-bit add of {0, c})
     return ((u64)xh << 32) | lo32(acc);
+}
+// y*w + h*(2^64 - q) + base  (mod 2^64); without base: congruent to y*w and in [0, 4q).  nq is always scalar (PrimeDev).
+template <bool TWS>
+__device__ __forceinline__ u64 mul_shoup4m_acc(u64 y, u64 w, u64 wp, u64 nq, u64 base)
+{
+    const u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
+    const u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
+    return shoup_rem_chain<TWS>(y, w, h, nq, base);
 }
 template <bool TWS>
 __device__ __forceinline__ u64 mul_shoup4m(u64 y, u64 w, u64 wp, u64 nq) { return mul_shoup4m_acc<TWS>(y, w, wp, nq, 0); }
@@ -281,7 +287,8 @@ __device__ __forceinline__ u64 reduce_2q(u64 x, const PrimeDev& p)
 {
     u32 t = (u32)(x >> p.red_sh1);
     u32 e = __umulhi(t, p.red_c) >> p.red_sh2;
-    return x + (u64)e * p.nq;      // e < 2^32: low 64 bits of e*nq added = x - e*q
+    // e < 2^32: low 64 bits of e*nq added = x - e*q
+    return x + (u64)e * p.nq;
 }
 
 // Same contract for primes q = 2^k - delta with small delta (k > 32, 2^(64-k) * delta + 2 delta < 2^k, checked on
@@ -462,6 +469,19 @@ constexpr unsigned WAVE_SLICE_WORDS = 1152;     // 2 half-waves x 32 rows x 18 w
 
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Two adjacent 64-bit words from two INDEPENDENT register pairs (ds_write2_b64, offsets in units of 8 bytes).  A 16-byte
+// store of (v[r], v[r+1]) as one ds_write_b128 needs the four VGPRs consecutive; the allocator cannot arrange that for all
+// sixteen pairs of a round's outputs and assembles the tuples with copies -- in the general-prime kernels with spills.
+// Inline asm: callers fence with wave_lds_fence() / a barrier before the words are read (the compiler's own waitcnt
+// insertion does not see these stores).
+template <int OFF8>
+__device__ __forceinline__ void lds_write2_u64(u64* addr, u64 a, u64 b)
+{
+    static_assert(OFF8 >= 0 && OFF8 + 1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
+    const u32 la = (u32)reinterpret_cast<uintptr_t>(addr);      // LDS addresses are 32-bit (the low half of the flat address)
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(la), "v"(a), "v"(b), "n"(OFF8), "n"(OFF8 + 1) : "memory");
+}
+
 // layout 5 -> layout 0.  Per half-wave (32 lanes) this is a 32x32 transpose: lane (h, c) holds M[r][c] in register r
 // and ends with row (its own c): M[c][0..31].  Two steps of 16 COLUMNS each: the lanes owning those columns store
 // all their registers (an exec-masked store), then every lane loads 16 words of its row.
@@ -506,7 +526,7 @@ __device__ __forceinline__ void wave_transpose_0_to_5(u64 (&v)[32], u64* slice, 
         if ((c >> 4) == (unsigned)step) {
             static_for<16>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
-                *reinterpret_cast<ulonglong2*>(wrow + 2 * m) = make_ulonglong2(v[2 * m], v[2 * m + 1]);
+                lds_write2_u64<2 * m>(wrow, v[2 * m], v[2 * m + 1]);
             });
         }
         wave_lds_fence();
@@ -540,8 +560,9 @@ __device__ __forceinline__ unsigned row_swz_store(unsigned row) { return row & 7
 // have (it was one of their spills, reloaded from scratch in front of the row store).
 __device__ __forceinline__ unsigned fresh_lane_id()
 {
-    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));          // opaque: recomputed at every use site instead of being hoisted out of the loop
+    unsigned l;                          // (volatile asm: emitted at every use site -- the builtins are computed once, hoisted
+                                         // out of the loop and spilled by the general-prime kernels)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
 
@@ -555,8 +576,7 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
         constexpr int ch = decltype(cc)::value;
         static_for<8>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            *reinterpret_cast<ulonglong2*>(base + lane * 128 + ((m ^ row_swz_store(lane)) << 4)) =
-                make_ulonglong2(v[16 * ch + 2 * m], v[16 * ch + 2 * m + 1]);
+            lds_write2_u64<0>(reinterpret_cast<u64*>(base + lane * 128 + ((m ^ row_swz_store(lane)) << 4)), v[16 * ch + 2 * m], v[16 * ch + 2 * m + 1]);
         });
         wave_lds_fence();
         static_for<8>([&](auto kc) {
@@ -665,19 +685,22 @@ __host__ __device__ constexpr int low_reg(int j, int k) { return ((k >> j) << (j
 #ifndef MI355NTT_RING_DEPTH_B0
 #define MI355NTT_RING_DEPTH_B0 2
 #endif
-template <int LOGN, int B>
+// TIGHT (exact-quotient general-prime inverse at n = 2^15: a full 64x64 high product and a 7-instruction partial reduction in
+// every stage need the registers): single butterflies, four buffers -- a prefetch distance of three butterflies out of 16
+// VGPRs instead of 32.
+template <int LOGN, int B, bool TIGHT = false>
 struct Ring {
-    static constexpr int GROUP = (B == 0 && LOGN == 15) ? MI355NTT_RING_GROUP_B0 : SCHED_GROUP;
-    static constexpr int DEPTH = (B == 0 && LOGN == 15) ? MI355NTT_RING_DEPTH_B0 : 2;
+    static constexpr int GROUP = TIGHT ? 1 : (B == 0 && LOGN == 15) ? MI355NTT_RING_GROUP_B0 : SCHED_GROUP;
+    static constexpr int DEPTH = TIGHT ? 4 : (B == 0 && LOGN == 15) ? MI355NTT_RING_DEPTH_B0 : 2;
 };
 
 // Twiddles of butterfly group G of a round (GROUP butterflies per group, 16 / GROUP groups per stage).
 // FWD: stages run j = JA, JA-1, ...; INV: j = JA, JA+1, ...
 // SCALE (inverse, last round only): the butterflies whose register bits JA .. j-1 are all zero have not met a twiddle in this
-// round yet -- they take theirs from p.twn, i.e. times n^-1 (see gs_round).
+// round yet -- they take theirs from twn (PrimeDev::twn of the modulus), i.e. times n^-1 (see gs_round).
 __host__ __device__ constexpr bool zero_history(int r0, int j, int jlo) { return ((r0 & ((1 << j) - 1)) >> jlo) == 0; }
 template <int LOGN, int B, int JA, bool FWD, int GROUP, int G, bool SCALE = false>
-__device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* __restrict__ tw, BufRsrc twr, unsigned thi, const PrimeDev& p)
+__device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* __restrict__ tw, BufRsrc twr, unsigned thi, const TwPair* __restrict__ twn)
 {
     constexpr int GPS = 16 / GROUP;                         // groups per stage
     constexpr int j = FWD ? JA - G / GPS : JA + G / GPS;
@@ -691,7 +714,7 @@ __device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* 
         W[k].w = 0x123456789abcdefULL + r0; W[k].wp = 0xfedcba987654321ULL + j; (void)tw; (void)twr; (void)thi;
 #else
         if constexpr (B == Geo<LOGN>::B0) {                 // group index independent of the thread: scalar load
-            if constexpr (SCALE && !FWD && zero_history(r0, j, JA)) W[k] = p.twn[len + u];
+            if constexpr (SCALE && !FWD && zero_history(r0, j, JA)) W[k] = twn[len + u];
             else W[k] = tw[len + u];
         } else
 #ifdef MI355NTT_ABLATE_TWL1     // timing experiment: same loads, every address inside one 4 KiB window (always L1 hits)
@@ -735,7 +758,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
     TwPair W[DEPTH][GROUP];
     static_for<DEPTH - 1>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
-        if constexpr (d < NG) load_tw_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi, p);
+        if constexpr (d < NG) load_tw_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi, nullptr);
     });
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -744,7 +767,7 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
         constexpr bool red = (RMASK >> s) & 1u;
         TwPair (&Wc)[GROUP] = W[g % DEPTH];
         prio_hook<PSPLIT, PAFTER, g>(t);
-        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, p);
+        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, nullptr);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -775,15 +798,17 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
 
 // Inverse (GS) stages on register bits JLO..4 of a layout with register field at bit B.
 template <int LOGN, int HL, int B, int JLO, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0>
-__device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
+__device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p,
+                                         const TwPair* __restrict__ twn)      // twn: &primes[idx].twn[0] -- read where it is used (last round only)
 {
     constexpr InvPolicy<LOGN, HL> POL{};
     constexpr bool EX = Lazy<HL>::EXACT;
-    constexpr int GROUP = Ring<LOGN, B>::GROUP, DEPTH = Ring<LOGN, B>::DEPTH, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
     constexpr bool VEC = (B != Geo<LOGN>::B0);
+    using RingT = Ring<LOGN, B, false>;
+    constexpr int GROUP = RingT::GROUP, DEPTH = RingT::DEPTH, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
     // The scaling by n^-1 (the reference halves in every stage, ntt_60bit.cuh:132,166,178) is folded into the twiddles of the
     // LAST round: in stage j the butterflies whose register bits JLO .. j-1 are zero hold values that have only been summed in
-    // this round so far; their difference output takes twiddle * n^-1 (p.twn), every later butterfly of that output uses the
+    // this round so far; their difference output takes twiddle * n^-1 (twn), every later butterfly of that output uses the
     // plain table.  What has been summed in all stages -- the registers below 2^JLO -- is multiplied by n^-1 in the last stage:
     // 2^JLO products per thread instead of 16.
     constexpr bool SCALE = !VEC;
@@ -791,7 +816,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
     TwPair W[DEPTH][GROUP];
     static_for<DEPTH - 1>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
-        if constexpr (d < NG) load_tw_group<LOGN, B, JLO, false, GROUP, d, SCALE>(W[d], tw, twr, thi, p);
+        if constexpr (d < NG) load_tw_group<LOGN, B, JLO, false, GROUP, d, SCALE>(W[d], tw, twr, thi, twn);
     });
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -802,7 +827,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
         const u64 cq = (u64)POL.cmul[beta] * p.q;
         TwPair (&Wc)[GROUP] = W[g % DEPTH];
         prio_hook<PSPLIT, PAFTER, g>(t);
-        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1, SCALE>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, p);
+        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1, SCALE>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, twn);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -815,10 +840,16 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
             constexpr bool fin_red = last && !(NEAR && !EX) && (2 * POL.cmul[beta] > Lazy<HL>::TQ);
             if constexpr (last && zero_history(r0, 5, JLO)) {
                 // summed in every stage of this round: the only values that still need an explicit n^-1
-                if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r0] = mul_shoup4m<true>(S, p.twn[0].w, p.twn[0].wp, p.nq);
-                else v[r0] = mul_shoup<EX>(S, p.twn[0].w, p.twn[0].wp, p.nq);
+                const TwPair ni = twn[0];
+                if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r0] = mul_shoup4m<true>(S, ni.w, ni.wp, p.nq);
+                else v[r0] = mul_shoup<EX>(S, ni.w, ni.wp, p.nq);
             } else {
-                if constexpr (red || fin_red) S = reduce_2q_sel<NEAR>(S, p);
+                if constexpr (red || fin_red) {
+                    // exact-quotient class: S < 4q always, one conditional subtraction of 2q (5 instructions, no multiply, fewer
+                    // temporaries than the general partial reduction -- with it these kernels spilled)
+                    if constexpr (EX && !NEAR) S = csub(S, 2 * p.q);
+                    else S = reduce_2q_sel<NEAR>(S, p);
+                }
                 v[r0] = S;
             }
             if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r1] = mul_shoup4m<!VEC>(D, Wc[k].w, Wc[k].wp, p.nq);
@@ -858,7 +889,7 @@ __device__ __forceinline__ void forward_core(u64 (&v)[32], const TwPair* tw, uns
 }
 
 template <int LOGN, int HL, int RHO, bool NEAR = false>
-__device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds)
+__device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds, const TwPair* twn)
 {
     using G = Geo<LOGN>;
     if constexpr (RHO < G::NR) {
@@ -870,17 +901,17 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             exchange<LOGN, BP, B>(v, lds, t);
             MI355NTT_STAMP(2 * RHO + 2);
         }
-        gs_round<LOGN, HL, B, LOW - B, NEAR>(v, tw, twr, t, p);
+        gs_round<LOGN, HL, B, LOW - B, NEAR>(v, tw, twr, t, p, twn);
         MI355NTT_STAMP(2 * RHO + 3);
-        inv_rounds<LOGN, HL, RHO + 1, NEAR>(v, tw, twr, t, p, lds);
+        inv_rounds<LOGN, HL, RHO + 1, NEAR>(v, tw, twr, t, p, lds, twn);
     }
 }
 
 // bit-reversed values in layout 0 (any representative below 2q... see callers) -> coefficients in layout B0, in [0, TQ*q)
 template <int LOGN, int HL, bool NEAR = false>
-__device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
+__device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds, const TwPair* twn)
 {
-    inv_rounds<LOGN, HL, 0, NEAR>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
+    inv_rounds<LOGN, HL, 0, NEAR>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds, twn);
 }
 
 // [0, TQ*q) -> [0, q).  Near-2^k primes: the 3-instruction fold brings [0, 4q) below 2q, so one compare/select pair
