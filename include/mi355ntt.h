@@ -154,7 +154,7 @@ int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, co
  * the exact transform, so those calls run the THROUGHPUT kernels: on first sight of a (device, n, moduli, mu,
  * bit_length, table address) the library reads the root out of the table, derives a context, compares the caller's
  * table with the derived one, and keeps the context (<= 32, least recently used evicted; first sight synchronises
- * the device).  Any other call (hand-made mu, a table that is not root^bitrev(i), a Barrett-inexact modulus, n outside
+ * the call's stream -- the table may have been filled asynchronously on it -- and reads the table from the host).  Any other call (hand-made mu, a table that is not root^bitrev(i), a Barrett-inexact modulus, n outside
  * 2^11..2^16, a table that is not 16-byte aligned) follows Algorithm 7 (singleBarrett, ntt_60bit.cuh:44-61) literally with the caller's
  * numbers: the literal kernels (the stages inside 2^14 coefficients out of LDS + one stage launch at n = 2^15 = 2 passes
  * over memory; the reference makes 4 and 5).
@@ -253,7 +253,8 @@ int mi355ntt_bfv_decrypt(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355
  * _decrypt leave for it (except that decryption also overwrites the second component's slot of the dropped last
  * prime, which the single driver leaves alone and nothing reads).  The secret key must hold all num_primes polynomials (keygen's output); plaintext of
  * ciphertext z: d_c + (z num_primes + num_primes - 2) n.  One fused product per component for the whole batch and one
- * launch per element-wise step, instead of the per-ciphertext launch sequence (which is bound by launch overhead). */
+ * launch per element-wise step, instead of the per-ciphertext launch sequence (which is bound by launch overhead).
+ * Limits: count <= 65535 and count * num_primes < 2^23; beyond them MI355NTT_EUNSUPPORTED, returned before d_c is touched. */
 int mi355ntt_bfv_encrypt_batch(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
                                const mi355ntt_u64* d_m, unsigned count, mi355ntt_stream stream);
 int mi355ntt_bfv_decrypt_batch(const mi355ntt_bfv* bfv, mi355ntt_u64* d_c, const mi355ntt_u64* d_secret_key, unsigned count,

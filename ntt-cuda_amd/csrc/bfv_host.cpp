@@ -212,6 +212,16 @@ int mi355ntt_bfv_decrypt(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355nt
     return MI355NTT_OK;
 }
 
+/* Limits of one batched call, checked up front so that a refused call leaves the ciphertexts untouched: the element-wise
+ * kernels put the ciphertext index in gridDim.z (<= 65535), the fused product's key-group size count * R rides in 23 bits of
+ * the division word (kernels.hpp, kSharedB), and 2 * count * R polynomials must not overflow the 32-bit polynomial count. */
+static bool bfv_batch_count_ok(unsigned count, unsigned R)
+{
+    if (count > 65535u) return false;
+    const unsigned long long group = (unsigned long long)count * R;
+    return group < (1ull << 23) && 2 * group <= 0xffffffffull;
+}
+
 /* ---- batched drivers: `count` ciphertexts per call, laid out [2][count][num_primes][n] (component-major, so that each
  * component of the whole batch is one contiguous run of polynomials for the fused product) ---- */
 int mi355ntt_bfv_encrypt_batch(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const mi355ntt_u64* d_public_key, const mi355ntt_u64* d_e,
@@ -220,6 +230,7 @@ int mi355ntt_bfv_encrypt_batch(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const m
     if (!b || !d_c || !d_public_key || !d_e || !d_m) return MI355NTT_EINVAL;
     if (count == 0) return MI355NTT_OK;
     const unsigned R = b->p.R;
+    if (!bfv_batch_count_ok(count, R)) return MI355NTT_EUNSUPPORTED;      /* before anything touches d_c */
     BFV_ON_DEVICE(b);
     /* :268-271 for the whole batch in one launch: the first count R polynomials with pk0, the rest with pk1 */
     BFV_RC(mi355ntt_polymul_batch_shared(b->ntt, d_c, d_public_key, 2 * count * R, R, count * R, stream));
@@ -233,6 +244,7 @@ int mi355ntt_bfv_decrypt_batch(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const m
     if (!b || !d_c || !d_secret_key) return MI355NTT_EINVAL;
     if (count == 0) return MI355NTT_OK;
     const unsigned R = b->p.R;
+    if (!bfv_batch_count_ok(count, R)) return MI355NTT_EUNSUPPORTED;      /* before anything touches d_c */
     const size_t half = (size_t)count * R * b->p.n;
     BFV_ON_DEVICE(b);
     /* bfv_decryption.cuh:98-101 on the c1 run of the batch; the slot of the dropped last prime is carried along unused */

@@ -506,7 +506,11 @@ void raw_entry_release(RawEntry& e)
 
 // The cache entry of this raw call (g_raw_mutex held by the caller); entry->ctx is the context that serves it with the
 // throughput kernels, or null (literal kernels).  Null when the routing is off.
-RawEntry* raw_lookup(unsigned n, unsigned division, bool inverse, const u64* d_tab, const u64* q, const u64* mu, const unsigned* bits)
+// `s` / `have_stream`: the stream the caller's table was (possibly asynchronously) written on -- first sight reads the table
+// from the host, so that stream is synchronised first (a table still being filled on a non-blocking stream would otherwise
+// fail the comparison and pin the entry to the literal kernels for good); without a stream the whole device is.
+RawEntry* raw_lookup(unsigned n, unsigned division, bool inverse, const u64* d_tab, const u64* q, const u64* mu, const unsigned* bits,
+                     hipStream_t s = nullptr, bool have_stream = false)
 {
     if (!raw_routing_enabled()) return nullptr;
     int device = 0;
@@ -519,6 +523,8 @@ RawEntry* raw_lookup(unsigned n, unsigned division, bool inverse, const u64* d_t
     RawEntry e;
     e.device = device; e.n = n; e.division = division; e.inverse = inverse; e.tab = d_tab;
     for (unsigned i = 0; i < division; i++) { e.q[i] = q[i]; e.mu[i] = mu[i]; e.bits[i] = bits[i]; }
+    if (have_stream) (void)hipStreamSynchronize(s);
+    else (void)hipDeviceSynchronize();
     e.ctx = raw_derive(device, n, division, inverse, d_tab, q, mu, bits);
     (void)hipGetLastError();
     e.stamp = ++g_raw_clock;
@@ -609,7 +615,7 @@ int mi355ntt_forward_batch_raw(mi355ntt_u64* d_a, unsigned n, const mi355ntt_u64
     if (num == 0) return MI355NTT_OK;
     (void)hipGetLastError();
     std::lock_guard<std::mutex> lock(g_raw_mutex);       // one call's launches stay together on the stream
-    HIP_TRY(raw_run(raw_lookup(n, division, false, d_tabs, q, mu, bits), false, d_a, n, d_tabs, num, division, m, (hipStream_t)s));
+    HIP_TRY(raw_run(raw_lookup(n, division, false, d_tabs, q, mu, bits, (hipStream_t)s, true), false, d_a, n, d_tabs, num, division, m, (hipStream_t)s));
     return MI355NTT_OK;
 }
 
@@ -625,7 +631,7 @@ int mi355ntt_inverse_batch_raw(mi355ntt_u64* d_a, unsigned n, const mi355ntt_u64
     if (num == 0) return MI355NTT_OK;
     (void)hipGetLastError();
     std::lock_guard<std::mutex> lock(g_raw_mutex);
-    HIP_TRY(raw_run(raw_lookup(n, division, true, d_tabs, q, mu, bits), true, d_a, n, d_tabs, num, division, m, (hipStream_t)s));
+    HIP_TRY(raw_run(raw_lookup(n, division, true, d_tabs, q, mu, bits, (hipStream_t)s, true), true, d_a, n, d_tabs, num, division, m, (hipStream_t)s));
     return MI355NTT_OK;
 }
 

@@ -123,6 +123,8 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 #if MI355NTT_SMALL_ROW_STAGING
     // rows (16-byte loads) through the wave's own 8 KiB of the image straight into layout 0: no layout exchange
     wave_load_rows(v, lds + (t >> 6) * 1024u, make_rsrc(a + (size_t)y * G::N, G::N * 8u), (t >> 6) * 16384u, 0u);
+    __syncthreads();        // every wave has left its staging slice: the first exchange writes the workgroup-wide image over them
+                            // (later iterations are covered by the barrier at the loop's end)
 #else
     load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
 #endif

@@ -189,7 +189,7 @@ k_ntt30_prepare(const u32* __restrict__ tab, unsigned n, u32 q, u32 ninv, unsign
         }
         sc->tw[dst] = make_uint2(w, shoup32_companion(w < q ? w : 0, q));
     }
-    if (bad) atomicMax(&sc->guard[1], epoch);
+    if (bad) sc->guard[1] = epoch;       // (every writer stores the same value; a plain store stays right when the host epoch wraps)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sc->guard[0] = epoch;
         sc->ninv = ninv;
@@ -601,6 +601,7 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
 
 // ---- scratch per (device, stream) -----------------------------------------------------------------------------------
 std::mutex g_scratch_mutex;
+std::mutex g_launch30_mutex;      // one for forward AND inverse calls: both directions share the (device, stream) scratch table
 std::map<std::pair<int, hipStream_t>, Scratch30*> g_scratch;
 unsigned g_epoch = 0;
 
@@ -691,8 +692,7 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     if (!sc) return hipErrorOutOfMemory;
     // the scratch table belongs to the (device, stream) pair: one call's prepare -> transform -> fallback sequence must
     // reach the stream as a unit even when several host threads share the stream
-    static std::mutex launch_mutex;
-    std::lock_guard<std::mutex> launch_lock(launch_mutex);
+    std::lock_guard<std::mutex> launch_lock(g_launch30_mutex);
     const unsigned epoch = next_epoch();
     const unsigned split = n == 65536 ? 1u : 0u;
     k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_native, split, FWD ? 1u : 0u, sc, epoch);
