@@ -411,6 +411,10 @@ struct SharedB {
 };
 __host__ __device__ inline unsigned plain_division(unsigned division) { return (division & kSharedB) ? (division & kDivisionMask) : division; }
 
+}  // namespace mi355ntt
+#include "kernels_lat15.cuh"      // the small-batch kernels of n = 2^15 (need SharedB)
+namespace mi355ntt {
+
 template <int HL, bool NEAR>
 __global__ void __launch_bounds__(1024, 4)
 k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
@@ -627,6 +631,17 @@ k_mul15_rows(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __
     static_for<32>([&](auto rc) { buf_store_u64(prs, voff, (unsigned)decltype(rc)::value * 256u, v[decltype(rc)::value]); });
 }
 
+// which small-batch kernels: 8 coefficients per thread (kernels_lat15.cuh, default) or round 1/2's 32 (MI355NTT_LATENCY_REGS=32:
+// kept for the A/B in profiles/r03_latency_cpp.txt)
+inline bool latency_path_uses_8()
+{
+    static const bool v = [] {
+        const char* e = std::getenv("MI355NTT_LATENCY_REGS");
+        return !(e && std::strtoul(e, nullptr, 10) == 32);
+    }();
+    return v;
+}
+
 // up to this many polynomials the two-launch latency path is used (the persistent kernels need >= one polynomial per CU
 // to pay off; at 16 one-wave workgroups per polynomial 64 polynomials already fill 1024 wave slots)
 inline unsigned latency_path_max_polys()
@@ -708,6 +723,25 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
+        if (num <= latency_path_max_polys() && latency_path_uses_8()) {
+#define MI355NTT_LAT8(K1, G1, B1, K2, G2, B2, H, N)                                         \
+            do {                                                                            \
+                K1<H, N><<<dim3(num * G1), dim3(B1), 0, s>>>(d_a, tw, pr, division, base);  \
+                K2<H, N><<<dim3(num * G2), dim3(B2), 0, s>>>(d_a, tw, pr, division, base);  \
+            } while (0)
+#define MI355NTT_LAT8_FWD(H, N) MI355NTT_LAT8(k_lat15_fwd_a, 8u, 512, k_lat15_fwd_b, 64u, 64, H, N)
+#define MI355NTT_LAT8_INV(H, N) MI355NTT_LAT8(k_lat15_inv_b, 64u, 64, k_lat15_inv_a, 8u, 512, H, N)
+            if (near) {
+                if (h >= 6) MI355NTT_LAT8_FWD(6, true);
+                else if (h >= 4) MI355NTT_LAT8_FWD(4, true);
+                else MI355NTT_LAT8_FWD(2, true);
+            } else {
+                if (h >= 6) MI355NTT_LAT8_FWD(6, false);
+                else if (h >= 4) MI355NTT_LAT8_FWD(4, false);
+                else MI355NTT_LAT8_FWD(2, false);
+            }
+            return hipGetLastError();
+        }
         if (num <= latency_path_max_polys()) {
             dim3 g2(num * 16u), b2(64);
 #define MI355NTT_LAT2(K1, K2, H, N)                                                         \
@@ -766,6 +800,18 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
+        if (num <= latency_path_max_polys() && latency_path_uses_8()) {
+            if (near) {
+                if (h >= 6) MI355NTT_LAT8_INV(6, true);
+                else if (h >= 4) MI355NTT_LAT8_INV(4, true);
+                else MI355NTT_LAT8_INV(2, true);
+            } else {
+                if (h >= 6) MI355NTT_LAT8_INV(6, false);
+                else if (h >= 4) MI355NTT_LAT8_INV(4, false);
+                else MI355NTT_LAT8_INV(2, false);
+            }
+            return hipGetLastError();
+        }
         if (num <= latency_path_max_polys()) {
             dim3 g2(num * 16u), b2(64);
             if (near) {
@@ -813,6 +859,25 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
         dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
+        if (num <= latency_path_max_polys() && latency_path_uses_8()) {
+#define MI355NTT_LAT8_MUL(H, N)                                                              \
+            do {                                                                             \
+                k_lat15_fwd_a<H, N><<<dim3(num * 8u), dim3(512), 0, s>>>(d_a, twf, pr, plain_division(division), 0u);   \
+                k_lat15_mul_b<H, N><<<dim3(num * 64u), dim3(64), 0, s>>>(d_a, d_b, twf, twi, pr, division);            \
+                k_lat15_inv_a<H, N><<<dim3(num * 8u), dim3(512), 0, s>>>(d_a, twi, pr, plain_division(division), 0u);   \
+            } while (0)
+            if (near) {
+                if (h >= 6) MI355NTT_LAT8_MUL(6, true);
+                else if (h >= 4) MI355NTT_LAT8_MUL(4, true);
+                else MI355NTT_LAT8_MUL(2, true);
+            } else {
+                if (h >= 6) MI355NTT_LAT8_MUL(6, false);
+                else if (h >= 4) MI355NTT_LAT8_MUL(4, false);
+                else MI355NTT_LAT8_MUL(2, false);
+            }
+#undef MI355NTT_LAT8_MUL
+            return hipGetLastError();
+        }
         if (num <= latency_path_max_polys()) {
             dim3 g2(num * 16u), b2(64);
 #define MI355NTT_LAT3(H, N)                                                                  \

@@ -39,7 +39,19 @@ int main(int argc, char** argv)
     std::vector<unsigned long long> a(N), b(N), refc(N);
     orc_splitmix_fill(a.data(), N, 21, q);       // the reference draws from an unseeded mt19937_64 (helper.h:72-83)
     orc_splitmix_fill(b.data(), N, 22, q);
-    orc_ref_polymul(a.data(), b.data(), refc.data(), q, N);                                                   // :65-66
+    if (N <= 8192) {
+        orc_ref_polymul(a.data(), b.data(), refc.data(), q, N);                                               // :65-66
+    } else {
+        // refPolyMul128 is O(n^2) (~9 min at n = 32768): above 8192 the expected product comes from the oracle's own
+        // forward -> pointwise -> inverse (ntt_60bit.cuh:314-386, poly_arithmetic.cuh:9-34 restated; itself pinned on the
+        // schoolbook product at the small sizes, tests/test_oracle_golden.py)
+        std::vector<unsigned long long> fb(b);
+        refc = a;
+        orc_forward(refc.data(), N, q, mu, bit_length, psiTable.data());
+        orc_forward(fb.data(), N, q, mu, bit_length, psiTable.data());
+        orc_pointwise(refc.data(), fb.data(), N, q, mu, bit_length);
+        orc_inverse(refc.data(), N, q, mu, bit_length, psiinvTable.data());
+    }
 
     unsigned long long *d_a, *d_b;
     HIPCK(hipMalloc(&d_a, size_array));
