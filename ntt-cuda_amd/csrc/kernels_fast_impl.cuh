@@ -487,170 +487,21 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     }
 }
 
-// ================================================================================================
-// n = 2^15, SMALL batches (latency path): the same rounds cut into two launches of one-wave workgroups so that a
-// single polynomial spreads over 16 CUs instead of one (the reference's own headline numbers are batch-1
-// latencies: 39 us NTT / 23 us INTT on V100, Article.pdf p25).  The workgroup-wide exchange is replaced by the
-// round trip through memory between the two launches: "cols" does the round on index bits 14..10 for 64 columns,
-// "rows" does the ten stages that stay inside 2048 consecutive coefficients, entirely wave-local.  Values travel
-// between the launches in lazy form [0, B*q); the compile-time bound tracking continues across them.
-// ================================================================================================
-template <int HL, bool NEAR>
-__global__ void __launch_bounds__(64, 1)
-k_fwd15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-             unsigned prime_base)
+// Small batches of n = 2^15 run the latency kernels (kernels_lat15.cuh: 64 waves per polynomial, two launches, twice the HBM
+// traffic), large ones the persistent single-pass kernels (one 1024-thread workgroup per CU walking the batch).  Measured
+// crossover on MI355X (profiles/r03_latency_cpp.txt): fwd+inv pairs 160 polynomials, fused products 176.  A persistent launch
+// costs whole iterations (ceil(num / CUs) polynomials per workgroup), so just above one polynomial per CU the latency kernels
+// win once more (320 polynomials: 142 us against 162 us per pair) until the second iteration is well filled.
+// MI355NTT_LATENCY_PATH_MAX in the environment replaces the rule by a plain threshold (tuning / tests: 0 = never).
+inline bool use_latency_path(unsigned num, bool fused)
 {
-    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
-    constexpr int LOGN = 15;
-    using G = Geo<LOGN>;
-    const unsigned y = blockIdx.x >> 4, t = ((blockIdx.x & 15u) << 6) | threadIdx.x;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    u64* poly = a + (size_t)y * G::N;
-    u64 v[32];
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly, t);
-    ct_round<LOGN, HL, 10, 4, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p);
-    store_coalesced<LOGN>(v, poly, t);
-}
-
-template <int HL, bool NEAR>
-__global__ void __launch_bounds__(64, 1)
-k_fwd15_rows(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-             unsigned prime_base)
-{
-    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
-    constexpr int LOGN = 15;
-    using G = Geo<LOGN>;
-    __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
-    const unsigned y = blockIdx.x >> 4, wave = blockIdx.x & 15u, lane = threadIdx.x, t = (wave << 6) | lane;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-    u64* poly = a + (size_t)y * G::N;
-    const BufRsrc prs = make_rsrc(poly, G::N * 8u);
-    u64 v[32];
-    // layout 5: register r of thread t holds coefficient ((t >> 5) << 10) | (r << 5) | (t & 31)
-    const unsigned voff = (((t >> 5) << 10) | (t & 31u)) * 8u;
-    static_for<32>([&](auto rc) { v[decltype(rc)::value] = buf_load_u64(prs, voff, (unsigned)decltype(rc)::value * 256u); });
-    ct_round<LOGN, HL, 5, 4, NEAR>(v, twp, twr, t, p);
-    wave_transpose_5_to_0(v, slice, lane);
-    ct_round<LOGN, HL, 0, 4, NEAR>(v, twp, twr, t, p);
-    static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
-    wave_store_rows(v, slice, prs, wave * 16384u, lane);
-}
-
-template <int HL, bool NEAR>
-__global__ void __launch_bounds__(64, 1)
-k_inv15_rows(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-             unsigned prime_base)
-{
-    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
-    constexpr int LOGN = 15;
-    using G = Geo<LOGN>;
-    __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
-    const unsigned y = blockIdx.x >> 4, wave = blockIdx.x & 15u, lane = threadIdx.x, t = (wave << 6) | lane;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-    u64* poly = a + (size_t)y * G::N;
-    const BufRsrc prs = make_rsrc(poly, G::N * 8u);
-    u64 v[32];
-    wave_load_rows(v, slice, prs, wave * 16384u, lane);
-    gs_round<LOGN, HL, 0, 0, NEAR>(v, twp, twr, t, p, primes[idx].twn);
-    wave_transpose_0_to_5(v, slice, lane);
-    gs_round<LOGN, HL, 5, 0, NEAR>(v, twp, twr, t, p, primes[idx].twn);
-    const unsigned voff = (((t >> 5) << 10) | (t & 31u)) * 8u;
-    static_for<32>([&](auto rc) { buf_store_u64(prs, voff, (unsigned)decltype(rc)::value * 256u, v[decltype(rc)::value]); });
-}
-
-template <int HL, bool NEAR>
-__global__ void __launch_bounds__(64, 1)
-k_inv15_cols(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
-             unsigned prime_base)
-{
-    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
-    constexpr int LOGN = 15;
-    using G = Geo<LOGN>;
-    const unsigned y = blockIdx.x >> 4, t = ((blockIdx.x & 15u) << 6) | threadIdx.x;
-    const unsigned idx = prime_base + y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* twp = tw + (size_t)idx * G::N;
-    u64* poly = a + (size_t)y * G::N;
-    u64 v[32];
-    load_coalesced<LOGN>(v, poly, t);
-    gs_round<LOGN, HL, 10, 0, NEAR>(v, twp, make_rsrc(twp, G::N * 16u), t, p, primes[idx].twn);
-    static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
-    store_coalesced<LOGN>(v, poly, t);
-}
-
-// Small fused products: the forward "rows" launch, the pointwise product and the inverse "rows" launch work on the same
-// 2048 consecutive coefficients of one wave -- one launch, no trip through memory in between:
-//   k_fwd15_cols -> k_mul15_rows -> k_inv15_cols   (3 launches instead of 5 for a = INTT(NTT(a) (.) bhat))
-template <int HL, bool NEAR>
-__global__ void __launch_bounds__(64, 1)
-k_mul15_rows(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
-             const PrimeDev* __restrict__ primes, unsigned division)
-{
-    const SharedB sb(division);
-    constexpr int LOGN = 15;
-    using G = Geo<LOGN>;
-    __shared__ __attribute__((aligned(16))) u64 slice[WAVE_SLICE_WORDS];
-    const unsigned y = blockIdx.x >> 4, wave = blockIdx.x & 15u, lane = threadIdx.x, t = (wave << 6) | lane;
-    const unsigned idx = y % division;
-    const PrimeDev p = primes[idx];
-    const TwPair* tf = twf + (size_t)idx * G::N;
-    const TwPair* ti = twi + (size_t)idx * G::N;
-    const BufRsrc tfr = make_rsrc(tf, G::N * 16u), tir = make_rsrc(ti, G::N * 16u);
-    const BufRsrc prs = make_rsrc(a + (size_t)y * G::N, G::N * 8u);
-    const BufRsrc brs = make_rsrc(bhat + (size_t)sb.index(y, idx, division) * G::N, G::N * 8u);
-    u64 v[32];
-    const unsigned voff = (((t >> 5) << 10) | (t & 31u)) * 8u;                    // layout 5, as k_fwd15_rows
-    static_for<32>([&](auto rc) { v[decltype(rc)::value] = buf_load_u64(prs, voff, (unsigned)decltype(rc)::value * 256u); });
-    ct_round<LOGN, HL, 5, 4, NEAR>(v, tf, tfr, t, p);
-    wave_transpose_5_to_0(v, slice, lane);
-    ct_round<LOGN, HL, 0, 4, NEAR>(v, tf, tfr, t, p);
-    {
-        u64 bb[16];
-        wave_load_rows_half<0>(bb, slice, brs, wave * 16384u, lane);
-        static_for<16>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            v[r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[r], p), p.q), bb[r], p.q, p.mu, p.k);   // poly_arithmetic.cuh:36-66
-        });
-        wave_load_rows_half<1>(bb, slice, brs, wave * 16384u, lane);
-        static_for<16>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            v[16 + r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[16 + r], p), p.q), bb[r], p.q, p.mu, p.k);
-        });
-    }
-    gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, t, p, primes[idx].twn);
-    wave_transpose_0_to_5(v, slice, lane);
-    gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, t, p, primes[idx].twn);
-    static_for<32>([&](auto rc) { buf_store_u64(prs, voff, (unsigned)decltype(rc)::value * 256u, v[decltype(rc)::value]); });
-}
-
-// which small-batch kernels: 8 coefficients per thread (kernels_lat15.cuh, default) or round 1/2's 32 (MI355NTT_LATENCY_REGS=32:
-// kept for the A/B in profiles/r03_latency_cpp.txt)
-inline bool latency_path_uses_8()
-{
-    static const bool v = [] {
-        const char* e = std::getenv("MI355NTT_LATENCY_REGS");
-        return !(e && std::strtoul(e, nullptr, 10) == 32);
+    static const long forced = [] {
+        const char* e = std::getenv("MI355NTT_LATENCY_PATH_MAX");
+        return e ? (long)std::strtoul(e, nullptr, 10) : -1L;
     }();
-    return v;
-}
-
-// up to this many polynomials the two-launch latency path is used (the persistent kernels need >= one polynomial per CU
-// to pay off; at 16 one-wave workgroups per polynomial 64 polynomials already fill 1024 wave slots)
-inline unsigned latency_path_max_polys()
-{
-    static const unsigned v = [] {
-        const char* e = std::getenv("MI355NTT_LATENCY_PATH_MAX");     // tuning/debug override
-        return e ? (unsigned)std::strtoul(e, nullptr, 10) : 128u;   // measured crossover on MI355X ~150 polynomials
-    }();
-    return v;
+    if (forced >= 0) return num <= (unsigned long)forced;
+    if (num <= (fused ? 176u : 160u)) return true;
+    return num > 256u && num <= (fused ? 384u : 352u);
 }
 
 // ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
@@ -723,7 +574,7 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
-        if (num <= latency_path_max_polys() && latency_path_uses_8()) {
+        if (use_latency_path(num, false)) {
 #define MI355NTT_LAT8(K1, G1, B1, K2, G2, B2, H, N)                                         \
             do {                                                                            \
                 K1<H, N><<<dim3(num * G1), dim3(B1), 0, s>>>(d_a, tw, pr, division, base);  \
@@ -739,24 +590,6 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
                 if (h >= 6) MI355NTT_LAT8_FWD(6, false);
                 else if (h >= 4) MI355NTT_LAT8_FWD(4, false);
                 else MI355NTT_LAT8_FWD(2, false);
-            }
-            return hipGetLastError();
-        }
-        if (num <= latency_path_max_polys()) {
-            dim3 g2(num * 16u), b2(64);
-#define MI355NTT_LAT2(K1, K2, H, N)                                                         \
-            do {                                                                            \
-                K1<H, N><<<g2, b2, 0, s>>>(d_a, tw, pr, division, base);                    \
-                K2<H, N><<<g2, b2, 0, s>>>(d_a, tw, pr, division, base);                    \
-            } while (0)
-            if (near) {
-                if (h >= 6) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 6, true);
-                else if (h >= 4) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 4, true);
-                else MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 2, true);
-            } else {
-                if (h >= 6) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 6, false);
-                else if (h >= 4) MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 4, false);
-                else MI355NTT_LAT2(k_fwd15_cols, k_fwd15_rows, 2, false);
             }
             return hipGetLastError();
         }
@@ -800,7 +633,7 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     if constexpr (LOGN == 15) {
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
-        if (num <= latency_path_max_polys() && latency_path_uses_8()) {
+        if (use_latency_path(num, false)) {
             if (near) {
                 if (h >= 6) MI355NTT_LAT8_INV(6, true);
                 else if (h >= 4) MI355NTT_LAT8_INV(4, true);
@@ -809,19 +642,6 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
                 if (h >= 6) MI355NTT_LAT8_INV(6, false);
                 else if (h >= 4) MI355NTT_LAT8_INV(4, false);
                 else MI355NTT_LAT8_INV(2, false);
-            }
-            return hipGetLastError();
-        }
-        if (num <= latency_path_max_polys()) {
-            dim3 g2(num * 16u), b2(64);
-            if (near) {
-                if (h >= 6) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 6, true);
-                else if (h >= 4) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 4, true);
-                else MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 2, true);
-            } else {
-                if (h >= 6) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 6, false);
-                else if (h >= 4) MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 4, false);
-                else MI355NTT_LAT2(k_inv15_rows, k_inv15_cols, 2, false);
             }
             return hipGetLastError();
         }
@@ -859,7 +679,7 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
         dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
         const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
         const int h = hl & 15;
-        if (num <= latency_path_max_polys() && latency_path_uses_8()) {
+        if (use_latency_path(num, true)) {
 #define MI355NTT_LAT8_MUL(H, N)                                                              \
             do {                                                                             \
                 k_lat15_fwd_a<H, N><<<dim3(num * 8u), dim3(512), 0, s>>>(d_a, twf, pr, plain_division(division), 0u);   \
@@ -876,26 +696,6 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
                 else MI355NTT_LAT8_MUL(2, false);
             }
 #undef MI355NTT_LAT8_MUL
-            return hipGetLastError();
-        }
-        if (num <= latency_path_max_polys()) {
-            dim3 g2(num * 16u), b2(64);
-#define MI355NTT_LAT3(H, N)                                                                  \
-            do {                                                                             \
-                k_fwd15_cols<H, N><<<g2, b2, 0, s>>>(d_a, twf, pr, plain_division(division), 0u);            \
-                k_mul15_rows<H, N><<<g2, b2, 0, s>>>(d_a, d_b, twf, twi, pr, division);                  \
-                k_inv15_cols<H, N><<<g2, b2, 0, s>>>(d_a, twi, pr, plain_division(division), 0u);            \
-            } while (0)
-            if (near) {
-                if (h >= 6) MI355NTT_LAT3(6, true);
-                else if (h >= 4) MI355NTT_LAT3(4, true);
-                else MI355NTT_LAT3(2, true);
-            } else {
-                if (h >= 6) MI355NTT_LAT3(6, false);
-                else if (h >= 4) MI355NTT_LAT3(4, false);
-                else MI355NTT_LAT3(2, false);
-            }
-#undef MI355NTT_LAT3
             return hipGetLastError();
         }
         if (near) {
