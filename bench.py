@@ -38,6 +38,10 @@ DEMO_Q16 = [18014398506729473, 36028797017456641, 36028797014704129, 36028797014
             36028797005135873, 36028797003694081, 36028797003563009, 36028797001138177]
 DEMO_PSI16 = [58232959302, 1155186985540, 631260524634, 1526647220035, 455957817523, 1650884166641, 10316746886, 768741990072,
               3911086673862, 5947090524825, 47595902954, 2691682578057, 3903338373, 235185854118, 1769787302793, 3151164484090]
+# the reference's getParams tuples (q, psi) used by the CPU-1 / CPU-2 rows of BASELINE.md 3 (parameter.h:38-47,73-77)
+REF_4096_58BIT = (288230376135196673, 60193018759093)
+REF_4096_25BIT = (33538049, 2386)
+REF_32768_55BIT = (36028797017456641, 1155186985540)
 HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_TRANSFORM = 2 * 32768 * 8   # one in-place transform reads and writes the polynomial once
 
@@ -57,8 +61,16 @@ def parse():
     return ap.parse_args()
 
 
+def synth_recipe(torch, ctx, num, n, device, seed_base):
+    """polynomial y = splitmix64(seed_base + y) mod q[y % P], generated on the device
+    (mi355ntt_synth_splitmix; the CPU oracle's synth_batch is the same recipe and the tests compare the two)"""
+    a = torch.empty((num, n), dtype=torch.int64, device=device)
+    ctx.synth_splitmix(a, num, seed_base)
+    return a
+
+
 def synth(torch, num, n, qs, device, seed):
-    """uniform residues: 60-bit randoms, one conditional subtraction (all q are within 2^-36 of 2^60)"""
+    """uniform residues for the extras (keys, second operands): 60-bit randoms, one conditional subtraction"""
     g = torch.Generator(device=device).manual_seed(seed)
     a = torch.randint(0, 1 << 60, (num, n), dtype=torch.int64, device=device, generator=g)
     qcol = torch.tensor(qs, dtype=torch.int64, device=device)[torch.arange(num, device=device) % len(qs)].unsqueeze(1)
@@ -109,6 +121,37 @@ def cpu_baseline(n, qs, psis):
                 break
         return num * reps / el, reps, el
 
+    # one polynomial, one thread, us per forward and per inverse
+    def single_poly_us(nn, q, psi, label):
+        one = oracle.Params(nn, [q], [psi])
+        x = oracle.synth_batch(nn, 1, [q], 1)[0].copy()
+        x0 = x.copy()
+        f, g = lib.orc_forward, lib.orc_inverse
+        for fn in (f, g):
+            fn.restype = None
+            fn.argtypes = [u64p, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, u64p]
+        args_f = (x.ctypes.data_as(u64p), nn, int(one.q[0]), int(one.mu[0]), int(one.k[0]), one.psi_tabs[0].ctypes.data_as(u64p))
+        args_i = (x.ctypes.data_as(u64p), nn, int(one.q[0]), int(one.mu[0]), int(one.k[0]), one.psiinv_tabs[0].ctypes.data_as(u64p))
+        f(*args_f); g(*args_i)
+        assert np.array_equal(x, x0)
+        reps = max(20, int(2.0e5 // nn) * 4)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f(*args_f)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g(*args_i)
+        t2 = time.perf_counter()
+        # (reps forwards then reps inverses of the same buffer: still the identity, checked)
+        assert np.array_equal(x, x0)
+        return {"config": label, "n": nn, "q": int(q), "bits": int(q).bit_length(), "forward_us": (t1 - t0) / reps * 1e6, "inverse_us": (t2 - t1) / reps * 1e6,
+                "pairs_per_s": reps / (t2 - t0)}
+
+    singles = [single_poly_us(4096, *REF_4096_58BIT, "CPU-1 n=4096, 58-bit (parameter.h:43-47)"),
+               single_poly_us(4096, *REF_4096_25BIT, "CPU-1 n=4096, 25-bit (parameter.h:38-42, the active set)"),
+               single_poly_us(32768, qs[0], psis[0], "CPU-2 n=32768, 60-bit (BASELINE configs[1])"),
+               single_poly_us(32768, *REF_32768_55BIT, "CPU-2 n=32768, 55-bit (parameter.h:73-77)")]
+
     # single thread first (the reference-style scalar rate), then OpenMP over polynomials at a few thread counts;
     # report the best aggregate and the threads it used
     single, _, _ = run(8, 1, 1.0)
@@ -123,9 +166,10 @@ def cpu_baseline(n, qs, psis):
         if rate > best[0]:
             best = (rate, th, num, reps, el)
     return {"value": best[0], "unit": "fwd+inv NTT pairs/s", "cores": best[1], "kind": "port",
-            "sample": "%d polys (n=%d, %d primes) x %d passes, OpenMP over polynomials, %.1f s wall; host has %d logical CPUs; "
-                      "rates by thread count: %s" % (best[2], n, len(qs), best[3], best[4], cores,
-                                                     ", ".join("%d: %.0f" % (k, v) for k, v in sorted(tried.items())))}
+            "sample": "CPU-3: %d polys (n=%d, %d primes) x %d passes, OpenMP over polynomials, %.1f s wall; host has %d logical CPUs; "
+                      "rates by thread count: %s; CPU-1 / CPU-2 (one polynomial, one thread) in single_polynomial_one_thread"
+                      % (best[2], n, len(qs), best[3], best[4], cores, ", ".join("%d: %.0f" % (k, v) for k, v in sorted(tried.items()))),
+            "single_polynomial_one_thread": singles}
 
 
 def bfv_round_trip(torch, ntt, n, dev, with_cpu, qs, psis, label):
@@ -281,7 +325,7 @@ def main():
     ctx = ntt.NTTContext(n, Q60, PSI60, device=local)
     # this rank's shard of the global batch: whole polynomials, shard size a multiple of the prime count so
     # polynomial y keeps prime y % P; inputs resident in HBM before timing starts
-    a = synth(torch, batch, n, Q60, dev, seed=1000 + rank)
+    a = synth_recipe(torch, ctx, batch, n, dev, seed_base=1 + rank * batch)      # seed = 1 + global polynomial index
     a0 = a.clone()
 
     def step():
@@ -341,8 +385,25 @@ def main():
         return b0.elapsed_time(b1) / args.steps
 
     fwd_ms = kernel_ms(lambda: ctx.forward_batch(a, batch))
+    fwd_clock_mhz = ctx.last_kernel_clock_mhz()         # sampled inside the last k_forward15 launch (s_memtime / s_memrealtime)
     inv_ms = kernel_ms(lambda: ctx.inverse_batch(a, batch))
+    inv_clock_mhz = ctx.last_kernel_clock_mhz()
     # `a` has now seen K forwards then K inverses: still a valid round trip
+    assert torch.equal(a, a0)
+
+    # ---- >= 20 interleaved rounds, median + min.  One round = ROUND_STEPS forward+inverse steps between two
+    # events; the rounds are queued back to back (no host synchronisation in between: the clocks stay where they are)
+    ROUNDS, ROUND_STEPS = 20, max(1, min(10, args.steps))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(ROUNDS + 1)]
+    for _ in range(10):
+        step()
+    evs[0].record()
+    for r in range(ROUNDS):
+        for _ in range(ROUND_STEPS):
+            step()
+        evs[r + 1].record()
+    torch.cuda.synchronize()
+    round_ms = sorted(evs[r].elapsed_time(evs[r + 1]) / ROUND_STEPS for r in range(ROUNDS))
     assert torch.equal(a, a0)
 
     pairs_per_s = world * batch * args.steps / elapsed
@@ -350,7 +411,7 @@ def main():
     alg_bytes = batch * BYTES_PER_TRANSFORM                       # per launch of either kernel
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9                  # GB/s
     traffic, traffic_source = None, None
-    for tname in ("traffic_r02.json", "traffic_r01.json"):
+    for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             try:
@@ -364,14 +425,23 @@ def main():
     # secondary (VALU) ceiling: issue cycles of the kernel's own instruction stream at the measured steady-state cost of
     # each instruction (tools/isa_cost.py over the shipped code object, tools/ubench_issue.hip), one polynomial per CU
     valu = {}
-    vpath = os.path.join(ROOT, "profiles", "valu_ceiling_r02.json")
+    vpath = os.path.join(ROOT, "profiles", "valu_ceiling_r03.json")
     if os.path.exists(vpath):
         try:
             valu = json.load(open(vpath))
         except Exception:
             valu = {}
-    vk = valu.get(dom_name, {})
-    valu_ceiling = vk.get("transforms_per_s")
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+
+    def ceiling(kname, clock_mhz):
+        """transforms/s of kernel `kname` if every issue slot of every SIMD were used: CUs x clock / issue cycles per polynomial
+        and CU, at the shader clock the kernel itself sampled during the timed launches"""
+        cyc = valu.get(kname, {}).get("cycles_per_polynomial_per_cu")
+        return (cus * clock_mhz * 1e6 / cyc) if (cyc and clock_mhz) else None
+
+    ceil_f, ceil_i = ceiling("k_forward15", fwd_clock_mhz), ceiling("k_inverse15", inv_clock_mhz)
+    valu_ceiling = ceil_f if dom_name == "k_forward15" else ceil_i
+    valu_pairs = (1.0 / (1.0 / ceil_f + 1.0 / ceil_i)) if (ceil_f and ceil_i) else None
     out = {
         "metric": "forward+inverse NTT/s (n=2^15, 60-bit q) per GPU; % HBM roofline",
         "value": pairs_per_s,
@@ -394,10 +464,19 @@ def main():
                      "pair_frac_of_hbm_peak": pairs_per_s / world * 2 * BYTES_PER_TRANSFORM / HBM_PEAK,
                      "valu_ceiling_transforms_per_s": valu_ceiling,
                      "frac_of_valu_ceiling": (batch / (dom_ms * 1e-3) / valu_ceiling) if valu_ceiling else None,
-                     "valu_ceiling_pairs_per_s": valu.get("pairs_per_s"),
-                     "pair_frac_of_valu_ceiling": (pairs_per_s / world / valu["pairs_per_s"]) if valu.get("pairs_per_s") else None,
-                     "valu_ceiling_source": valu.get("source")},
+                     "valu_ceiling_pairs_per_s": valu_pairs,
+                     "pair_frac_of_valu_ceiling": (pairs_per_s / world / valu_pairs) if valu_pairs else None,
+                     "in_kernel_clock_mhz": {"k_forward15": fwd_clock_mhz, "k_inverse15": inv_clock_mhz,
+                                             "how": "first workgroup of the last timed launch: s_memtime (shader cycles) over s_memrealtime (100 MHz) between kernel entry and exit"},
+                     "compute_units": cus,
+                     "valu_ceiling_source": "profiles/valu_ceiling_r03.json (tools/valu_ceiling.py: measured issue cycles per instruction summed over the shipped "
+                                            "kernels' polynomial loops) x compute_units x in_kernel_clock_mhz of this run"},
         "kernel_ms": {"k_forward15": fwd_ms, "k_inverse15": inv_ms, "step_by_events": step_ms_events},
+        "rounds": {"what": "%d rounds of %d forward+inverse steps each, queued back to back, HIP events between rounds (BASELINE.md 2)" % (ROUNDS, ROUND_STEPS),
+                   "pairs_per_s_median": world * batch / (round_ms[ROUNDS // 2] * 1e-3), "pairs_per_s_best": world * batch / (round_ms[0] * 1e-3),
+                   "pairs_per_s_worst": world * batch / (round_ms[-1] * 1e-3),
+                   "ms_per_step_median": round_ms[ROUNDS // 2], "ms_per_step_min": round_ms[0], "ms_per_step_max": round_ms[-1],
+                   "scope": "this rank" if world > 1 else "the GPU"},
         "cold_20_steps_pairs_per_s": cold_pairs_per_s * world,
     }
     if rank == 0 and world == 1 and not args.no_extras:
@@ -466,6 +545,25 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         mul_ms = e0.elapsed_time(e1) / 20
+        # the same fused product on the headline batch (1024 polynomials): fraction of the HBM peak on the graded unit
+        # (1 310 720 B: forward, product, inverse as three in-place operations) and on what the fused kernel moves (786 432 B)
+        bN = synth_recipe(torch, ctx, batch, n, dev, seed_base=5_000_001)
+        bhN = synth_recipe(torch, ctx, batch, n, dev, seed_base=6_000_001)
+        for _ in range(30):
+            ctx.polymul_batch(bN, bhN, batch)
+        e0.record()
+        for _ in range(40):
+            ctx.polymul_batch(bN, bhN, batch)
+        e1.record()
+        torch.cuda.synchronize()
+        mulN_ms = e0.elapsed_time(e1) / 40
+        mul_clock = ctx.last_kernel_clock_mhz()         # (k_polymul15 does not sample; this is the last transform's figure)
+        polymul = {"batch": batch, "ms_per_launch": mulN_ms, "products_per_s": batch / (mulN_ms * 1e-3),
+                   "polymul_frac": batch * 1310720 / (mulN_ms * 1e-3) / HBM_PEAK,
+                   "polymul_frac_fused_bytes": batch * 786432 / (mulN_ms * 1e-3) / HBM_PEAK,
+                   "vs_forward_plus_inverse_ms": fwd_ms + inv_ms,
+                   "units": "fraction of 8.0 TB/s on 1 310 720 B (SURVEY 8d graded unit) and on 786 432 B (what one fused pass moves)"}
+        del bN, bhN
         one = synth(torch, 1, n, Q60[:1], dev, seed=9)
 
         def lat(fn):
@@ -482,7 +580,20 @@ def main():
         pair_us = lat(lambda: (ctx.forward(one, 0), ctx.inverse(one, 0)))
         fwd_us = lat(lambda: ctx.forward(one, 0))
         inv_us = lat(lambda: ctx.inverse(one, 0))
+        # the small-batch paths timed from compiled C++ through the C ABI (tools/lat_bench.cpp, built by the package Makefile):
+        # per-call time on a stream, as one captured hipGraph, and call + wait; the Python figures beside it
+        cpp_lat = None
+        lat_exe = os.path.join(ROOT, "ntt-cuda_amd", "build", "lat_bench")
+        if os.path.exists(lat_exe):
+            try:
+                torch.cuda.synchronize()
+                r = subprocess.run([lat_exe, "200", "5"], capture_output=True, text=True, timeout=300)
+                cpp_lat = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as exc:
+                cpp_lat = {"error": repr(exc)}
         out["extras"] = {"config2_fused_polymul_batch256_per_s": 256 / (mul_ms * 1e-3), "config2_fused_polymul_ms": mul_ms,
+                         "fused_polymul_headline_batch": polymul,
+                         "latency_compiled_cpp": cpp_lat,
                          "config1_batch1_fwd_inv_pair_us": pair_us, "config1_batch1_forward_us": fwd_us,
                          "config1_batch1_inverse_us": inv_us,
                          "reference_published_v100_us": {"forward": 39, "inverse": 23, "source": "Article.pdf p25 Table 6 (55-bit q)"},

@@ -145,6 +145,18 @@ int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, co
                                   unsigned num, unsigned division, unsigned group, mi355ntt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Measurement helpers (no reference counterpart: the reference's programs draw inputs on the host, 60bit_ntt_test.cu:52-60)
+ * ---------------------------------------------------------------------------------------------- */
+/* Synthetic inputs of the benchmark recipe, generated on the context's device: polynomial y of d_a [num][n] receives the
+ * splitmix64 stream of seed seed_base + y reduced mod q[y % division] (state x0 = seed,
+ * x += 0x9E3779B97F4A7C15 per value, value = mix(x) mod q). */
+int mi355ntt_synth_splitmix(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned num, unsigned division,
+                            mi355ntt_u64 seed_base, mi355ntt_stream stream);
+/* Shader clock (MHz) the context's last batched n = 2^15 transform launch ran at, sampled inside the kernel (first workgroup:
+ * shader-cycle counter against the 100 MHz constant clock at entry and exit).  Synchronises the device.  0 = no sample. */
+int mi355ntt_ctx_last_kernel_clock_mhz(const mi355ntt_ctx* ctx, double* mhz);
+
+/* ------------------------------------------------------------------------------------------------
  * Raw-parameter entry points: signature-compatible with the reference (the caller supplies q, mu, bit_length and
  * reference-format device tables on every call, ntt_60bit.cuh:314,350,608,652 + the __constant__ moduli of :8-10).
  *

@@ -392,6 +392,35 @@ int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* c, mi355ntt_u64* d_a, cons
     return MI355NTT_OK;
 }
 
+/* ---------------- measurement helpers ---------------- */
+/* synthetic inputs of SURVEY.md 4.2 / 8d on the context's device: polynomial y = splitmix64(seed_base + y) mod q[y % division] */
+int mi355ntt_synth_splitmix(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned num, unsigned division, mi355ntt_u64 seed_base,
+                            mi355ntt_stream s)
+{
+    int rc = check_batch(c, d_a, num, division);
+    if (rc) return rc;
+    ON_CTX_DEVICE(c);
+    HIP_TRY(compat_synth_splitmix(d_a, c->n, num, division, mods_from(c, 0, division), seed_base, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+
+/* Shader clock of the context's last n = 2^15 persistent transform launch (k_forward15 / k_inverse15), measured by the kernel
+ * itself: its first workgroup stores s_memtime (shader cycles) and s_memrealtime (100 MHz) when it enters and when it leaves
+ * (kernels_fast_impl.cuh, kernel_clock_mark).  Blocks until the device has finished (a host read).  *mhz = 0 when no such
+ * launch has run on this context. */
+int mi355ntt_ctx_last_kernel_clock_mhz(const mi355ntt_ctx* c, double* mhz)
+{
+    if (!c || !mhz) return MI355NTT_EINVAL;
+    *mhz = 0.0;
+    if (!c->fast.d_primes_alloc) return MI355NTT_OK;
+    ON_CTX_DEVICE(c);
+    unsigned long long w[4] = {0, 0, 0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(w, static_cast<const char*>(c->fast.d_primes_alloc) + 16, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[3] > w[1] && w[2] > w[0]) *mhz = (double)(w[2] - w[0]) / (double)(w[3] - w[1]) * 100.0;
+    return MI355NTT_OK;
+}
+
 /* ---------------- raw-parameter entry points ---------------- */
 static int fill_modset(ModSet* m, unsigned division, const mi355ntt_u64* q, const mi355ntt_u64* mu, const unsigned* bits)
 {

@@ -8,6 +8,21 @@ namespace mi355ntt {
 
 constexpr unsigned kMaxPrimes = 16;
 
+// compute units of the CURRENT device (every launching entry point has switched to the context's device: device_scope.hpp);
+// sizes the persistent grids.  Cached per host thread and device; 256 (MI355X) only if the query itself fails.
+inline unsigned current_device_cus()
+{
+    static thread_local int cached_dev = -1;
+    static thread_local unsigned cached_cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
+        int v = 0;
+        cached_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (unsigned)v : 256u;
+        cached_dev = dev;
+    }
+    return cached_cus;
+}
+
 // Per-launch copy of the moduli: replaces the reference's __constant__ q_cons / mu_cons / q_bit_cons
 // (ntt_60bit.cuh:8-10).  Passed by value in the kernel argument segment (SGPR-resident).
 struct ModSet {
@@ -41,6 +56,8 @@ hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned len
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
                             const ModSet& m, hipStream_t s, bool shared_b = false, unsigned group = 0);
 hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s);
+// a[y][i] = splitmix64(seed_base + y)_i mod q[y % division]: the synthetic inputs of SURVEY.md 4.2 / 8d, generated on the device
+hipError_t compat_synth_splitmix(u64* d_a, unsigned n, unsigned num, unsigned division, const ModSet& m, u64 seed_base, hipStream_t s);
 // *d_flag |= 1 when two sets of `count` reference-format tables differ in an entry the transforms read (index != 0)
 hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_flag, hipStream_t s);
 // the same as a stream-ordered check: guard[0] = epoch, and guard[1] = epoch when the tables differ

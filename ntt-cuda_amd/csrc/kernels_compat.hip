@@ -12,6 +12,8 @@
 #include <cstdint>
 
 #include "kernels.hpp"
+
+#include <algorithm>
 #include "modarith.cuh"
 
 namespace mi355ntt {
@@ -219,11 +221,11 @@ void launch_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsi
     else gs_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, sh, blocks, m, guard);
 }
 
-// workgroups of the LDS kernel: as many as can be resident (160 KiB of LDS per CU, 256 CUs), each strides over the slices
+// workgroups of the LDS kernel: as many as can be resident (160 KiB of LDS per CU), each strides over the slices
 unsigned lds_grid(unsigned slices, int logs)
 {
     const unsigned per_cu = 163840u / (8u << logs) ? 163840u / (8u << logs) : 1u;
-    const unsigned cap = 256u * (per_cu > 2 ? 2 : per_cu);          // 1024-thread workgroups: at most two per CU
+    const unsigned cap = current_device_cus() * (per_cu > 2 ? 2 : per_cu);          // 1024-thread workgroups: at most two per CU
     return slices < cap ? slices : cap;
 }
 
@@ -311,6 +313,31 @@ hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n
 hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s)
 {
     pointwise_scalar_kernel<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(d_a, b, n, q, mu, k);
+    return hipGetLastError();
+}
+
+// Synthetic inputs of the measurement recipe: polynomial y = splitmix64 stream of seed seed_base + y,
+// value i = z_i mod q[y % division] (z_i = the i-th output; the state after i + 1 steps is seed + (i + 1) * golden ratio).
+__global__ void __launch_bounds__(kBlock) synth_splitmix_kernel(u64* __restrict__ a, unsigned n, unsigned num, unsigned division, ModSet m,
+                                                                u64 seed_base)
+{
+    const size_t total = (size_t)num * n;
+    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < total; g += (size_t)gridDim.x * kBlock) {
+        const unsigned y = (unsigned)(g / n), i = (unsigned)(g % n);
+        u64 z = seed_base + y + (u64)(i + 1) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        a[g] = z % m.q[y % division];
+    }
+}
+
+hipError_t compat_synth_splitmix(u64* d_a, unsigned n, unsigned num, unsigned division, const ModSet& m, u64 seed_base, hipStream_t s)
+{
+    if (num == 0) return hipSuccess;
+    const size_t total = (size_t)num * n;
+    const unsigned grid = (unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 65536);
+    synth_splitmix_kernel<<<grid, kBlock, 0, s>>>(d_a, n, num, division, m, seed_base);
     return hipGetLastError();
 }
 

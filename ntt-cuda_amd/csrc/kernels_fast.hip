@@ -89,7 +89,9 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         d.red_c = (u32)((((u128)1) << (31 + pp.k)) / pp.q);
         // near-2^k shape: q = 2^k - delta, k > 32, delta < 2^24 and 2^(64-k) * delta + 2 * delta < 2^k (reduce_2q_near)
         const u128 dl = (((u128)1) << pp.k) - pp.q;
-        const bool near_ok = pp.k > 32 && dl < ((u128)1 << 24) && ((dl << (64 - pp.k)) + 2 * dl) < (((u128)1) << pp.k);
+        // ... and 2 delta^2 + 3 delta < 2^k (mul_fold_near: the fused products' fold multiplication)
+        const bool near_ok = pp.k > 32 && dl < ((u128)1 << 24) && ((dl << (64 - pp.k)) + 2 * dl) < (((u128)1) << pp.k) &&
+                             (2 * dl * dl + 3 * dl) < (((u128)1) << pp.k);
         d.delta = near_ok ? (u32)dl : 0;
         d.near_sh = pp.k > 32 ? pp.k - 32 : 0;
         d.near_mask = pp.k > 32 ? (u32)((1ull << (pp.k - 32)) - 1) : 0;

@@ -278,6 +278,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
+    kernel_clock_mark(primes - 1, 0);
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_FWD, MI355NTT_STAGGER_FWD_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
@@ -324,6 +325,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
     }
+    kernel_clock_mark(primes - 1, 1);
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }
@@ -346,6 +348,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64 v[32];
     unsigned y = blockIdx.x;
     if (y >= num) return;
+    kernel_clock_mark(primes - 1, 0);
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
@@ -389,6 +392,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
     }
+    kernel_clock_mark(primes - 1, 1);
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }
@@ -464,16 +468,16 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
             wave_load_rows_half<0>(bb, slice, brs, 0u, 0u);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                v[r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[r], p), p.q), bb[r], p.q, p.mu, p.k);   // poly_arithmetic.cuh:36-66
+                v[r] = FusedMul<HL, NEAR>::mul(v[r], bb[r], p);
             });
             wave_load_rows_half<1>(bb, slice, brs, 0u, 0u);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                v[16 + r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[16 + r], p), p.q), bb[r], p.q, p.mu, p.k);
+                v[16 + r] = FusedMul<HL, NEAR>::mul(v[16 + r], bb[r], p);
             });
         }
         // ---- inverse ----
-        gs_round<LOGN, HL, 0, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
+        gs_round<LOGN, HL, 0, 0, NEAR, -2, 0, FusedMul<HL, NEAR>::LAZY>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         wave_transpose_0_to_5(v, slice, fresh_lane_id());
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
         gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
@@ -527,13 +531,11 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
 #pragma unroll
     for (int r = 0; r < 32; r += 2) {
         const TwPair bb = buf_load_tw(brs, t * 256u, (unsigned)r * 8u);      // two consecutive words of bhat
-        const u64 x0 = canon_2q(reduce_2q_sel<NEAR>(v[r], p), p.q);
-        const u64 x1 = canon_2q(reduce_2q_sel<NEAR>(v[r + 1], p), p.q);
-        v[r] = barrett_mul(x0, bb.w, p.q, p.mu, p.k);          // poly_arithmetic.cuh:36-66, Algorithm 7
-        v[r + 1] = barrett_mul(x1, bb.wp, p.q, p.mu, p.k);
+        v[r] = FusedMul<HL, NEAR>::mul(v[r], bb.w, p);
+        v[r + 1] = FusedMul<HL, NEAR>::mul(v[r + 1], bb.wp, p);
         if ((r & 6) == 6) __builtin_amdgcn_sched_barrier(0);
     }
-    inverse_core<LOGN, HL, NEAR>(v, twi + (size_t)idx * G::N, t, p, lds, primes[idx].twn);
+    inverse_core<LOGN, HL, NEAR, FusedMul<HL, NEAR>::LAZY>(v, twi + (size_t)idx * G::N, t, p, lds, primes[idx].twn);
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL, NEAR>(v[r], p);
     store_coalesced<LOGN>(v, poly, t);
@@ -549,14 +551,7 @@ inline unsigned persistent_grid(unsigned num)
     const unsigned by_lds = 163840u / (G::LDS_WORDS * 8u);
     unsigned per_cu = by_waves < by_lds ? by_waves : by_lds;
     if (per_cu < 1) per_cu = 1;
-    static thread_local int cached_dev = -1, cached_cus = 256;                      // CU count of the current device
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
-        int v = 0;
-        cached_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-        cached_dev = dev;
-    }
-    const unsigned cap = (unsigned)cached_cus * per_cu;
+    const unsigned cap = current_device_cus() * per_cu;
     return num < cap ? num : cap;
 }
 

@@ -58,14 +58,15 @@ __device__ __forceinline__ void lat_ct(u64& a, u64& b, const TwPair w, const Pri
 }
 
 // GS stage on index bit BETA: (a, b) <- (a + b, (a + cq - b) * w); FIN: the sum is what leaves the transform (last stage)
-template <int HL, bool NEAR, bool TWS, int BETA>
+template <int HL, bool NEAR, bool TWS, int BETA, bool IN2Q = false>
 __device__ __forceinline__ void lat_gs(u64& a, u64& b, const TwPair w, const PrimeDev& p)
 {
+    static_assert(!IN2Q || !Lazy<HL>::EXACT, "lazy inputs: classes with 4q of headroom only (gs_round, ntt_core.cuh)");
     constexpr InvPolicy<15, HL> POL{};
     constexpr bool EX = Lazy<HL>::EXACT;
     constexpr bool last = (BETA == 14);
     constexpr bool red = ((POL.mask >> BETA) & 1u) || (last && !(NEAR && !EX) && (2 * POL.cmul[BETA] > Lazy<HL>::TQ));
-    const u64 cq = (u64)POL.cmul[BETA] * p.q;
+    const u64 cq = (u64)((IN2Q && BETA == 0) ? 2 : POL.cmul[BETA]) * p.q;
     const u64 X = a, Y = b;
     u64 S = X + Y;
     const u64 D = X + cq - Y;
@@ -164,7 +165,7 @@ __device__ __forceinline__ void lat_fwd_round(u64 (&v)[8], const TwPair* __restr
 // Inverse round on index bits LOW, LOW+1, LOW+2 = register bits 0, 1, 2; upper = i >> (LOW + 3).  SCALE (the last round,
 // bits 12..14, upper = 0): butterflies whose lower register bits are zero take twiddle * n^-1 from twn (gs_round,
 // ntt_core.cuh), and register 0 -- summed in all three stages -- is multiplied by n^-1 itself.
-template <int HL, bool NEAR, bool UNI, int LOW, bool SCALE = false>
+template <int HL, bool NEAR, bool UNI, int LOW, bool SCALE = false, bool IN2Q = false>
 __device__ __forceinline__ void lat_inv_round(u64 (&v)[8], const TwPair* __restrict__ tw, BufRsrc twr, const PrimeDev& p, unsigned upper,
                                               const TwPair* __restrict__ twn = nullptr)
 {
@@ -184,7 +185,7 @@ __device__ __forceinline__ void lat_inv_round(u64 (&v)[8], const TwPair* __restr
             constexpr int k = decltype(kc)::value;
             constexpr int r0 = low_reg(rb, k), r1 = r0 | (1 << rb);
             constexpr bool zero_hist = SCALE && ((r0 & ((1 << rb) - 1)) == 0);
-            lat_gs<HL, NEAR, UNI, beta>(v[r0], v[r1], zero_hist ? Wn[r0 >> (rb + 1)] : W[r0 >> (rb + 1)], p);
+            lat_gs<HL, NEAR, UNI, beta, IN2Q>(v[r0], v[r1], zero_hist ? Wn[r0 >> (rb + 1)] : W[r0 >> (rb + 1)], p);
         });
     });
     if constexpr (SCALE) v[0] = lat_scale<HL, UNI>(v[0], twn[0], p);
@@ -290,10 +291,10 @@ __device__ __forceinline__ void lat_fwd_b_rounds(u64 (&v)[8], const TwPair* twp,
     lat_fwd_round<HL, NEAR, false, 2>(v, twp, twr, p, (c << 6) | lane);
 }
 // bits 0..8 inverse on registers: in L0, out L6
-template <int HL, bool NEAR>
+template <int HL, bool NEAR, bool IN2Q = false>
 __device__ __forceinline__ void lat_inv_b_rounds(u64 (&v)[8], const TwPair* twp, BufRsrc twr, const PrimeDev& p, u64* slice, unsigned c, unsigned lane)
 {
-    lat_inv_round<HL, NEAR, false, 0>(v, twp, twr, p, (c << 6) | lane);
+    lat_inv_round<HL, NEAR, false, 0, false, IN2Q>(v, twp, twr, p, (c << 6) | lane);
     lat_t_03(v, slice, lane);
     lat_inv_round<HL, NEAR, false, 3>(v, twp, twr, p, (c << 3) | (lane >> 3));
     lat_t_36(v, slice, lane);
@@ -358,9 +359,9 @@ k_lat15_mul_b(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* _
     lat_fwd_b_rounds<HL, NEAR>(v, tf, tfr, p, slice, c, lane);
     static_for<8>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        v[r] = barrett_mul(canon_2q(reduce_2q_sel<NEAR>(v[r], p), p.q), bb[r], p.q, p.mu, p.k);
+        v[r] = FusedMul<HL, NEAR>::mul(v[r], bb[r], p);
     });
-    lat_inv_b_rounds<HL, NEAR>(v, ti, tir, p, slice, c, lane);
+    lat_inv_b_rounds<HL, NEAR, FusedMul<HL, NEAR>::LAZY>(v, ti, tir, p, slice, c, lane);
     lat_store_l6(v, prs, c, lane);
 }
 

@@ -18,6 +18,25 @@
 
 #include "modarith.cuh"
 
+// ---- the lab is not the product ---------------------------------------------------------------------------------------
+// The kernels carry compile-time switches for measurement builds (tools/kbench.hip via tools/build_kbench.sh): ablations
+// that produce WRONG RESULTS (MI355NTT_ABLATE_*), in-kernel time stamps, tuning knobs (priorities, stagger, cache policy,
+// ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
+// CXXFLAGS then stops the compilation instead of shipping a different kernel.
+#ifndef MI355NTT_LAB
+#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || \
+    defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
+    defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
+    defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \
+    defined(MI355NTT_SMALL_ROW_STAGING) || defined(MI355NTT_FWD_LOAD_PAIR16) || defined(MI355NTT_PRIO_R1) || defined(MI355NTT_PRIO_I1) || \
+    defined(MI355NTT_PSPLIT_R1) || defined(MI355NTT_PSPLIT_R2) || defined(MI355NTT_PSPLIT_R3) || defined(MI355NTT_PSPLIT_I1) || \
+    defined(MI355NTT_PSPLIT_I2) || defined(MI355NTT_PSPLIT_I3) || defined(MI355NTT_STAGGER_FWD) || defined(MI355NTT_STAGGER_INV) || \
+    defined(MI355NTT_STAGGER_FWD_MULTI) || defined(MI355NTT_STAGGER_INV_MULTI) || defined(MI355NTT_STAGGER_MUL) || \
+    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_DESCENDING)
+#error "MI355NTT_* experiment switches are for measurement builds only: add -DMI355NTT_LAB (tools/build_kbench.sh); a library build must not define them"
+#endif
+#endif
+
 namespace mi355ntt {
 
 // Compile-time loop: the body receives std::integral_constant<int, I>, so every register-array index below
@@ -88,6 +107,22 @@ constexpr unsigned kWgLogCap = 1u << 16;
 #define MI355NTT_STAMP_DECL
 #define MI355NTT_STAMP_FLUSH
 #endif
+
+// In-kernel clock sample of the persistent n = 2^15 kernels: the first lane of workgroup 0 stores the shader-cycle counter and
+// the 100 MHz constant clock at entry (slot 0) and at exit (slot 1) into the guard record in front of the PrimeDev array
+// (bytes 16..47; bytes 0..7 are the guard words of the checked raw calls).  mi355ntt_ctx_last_kernel_clock_mhz reads them:
+// bench.py prices its VALU ceiling at the clock the timed launches actually ran at.  Cost: two scalar clock reads and one
+// 16-byte store per launch and mark.
+__device__ __forceinline__ void kernel_clock_mark(const void* primes_base, unsigned slot)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long tm, rt;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm), "=s"(rt) :: "memory");
+        unsigned long long* c = reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(primes_base)) + 2 + 2 * slot;
+        c[0] = tm;
+        c[1] = rt;
+    }
+}
 
 struct TwPair {       // {w, floor(w * 2^64 / q)}
     u64 w, wp;
@@ -305,6 +340,26 @@ __device__ __forceinline__ u64 reduce_2q_sel(u64 x, const PrimeDev& p)
 {
     if constexpr (NEAR) return reduce_2q_near(x, p);
     else return reduce_2q(x, p);
+}
+
+// x * b mod q for DATA operands (no Shoup companion: the second operand of the fused products) and q = 2^k - delta:
+// x in [0, 2q), b < 2^k  ->  congruent value in [0, 2q).  The 128-bit product is folded twice with 2^k = delta (mod q):
+//   P = Phi 2^k + Plo,  F = Phi delta + Plo < 2^(k+26),  F = T 2^k + R,  result = T delta + R
+// 7 multiply-adds, 3 funnel shifts, 2 masks -- Algorithm 7 on canonical operands (barrett_mul, poly_arithmetic.cuh:36-66) costs
+// about twice that plus the canonicalisation of x.  Needs 2 delta^2 + 3 delta < 2^k, part of the near-2^k test on the host
+// (fast_tables_create); every step is exact, so the transform's canonical output is the reference's.
+__device__ __forceinline__ u64 mul_fold_near(u64 x, u64 b, const PrimeDev& p)
+{
+    u64 lo, hi;
+    mul_wide(x, b, lo, hi);
+    const u32 w0 = lo32(lo), w1 = hi32(lo), w2 = lo32(hi), w3 = hi32(hi);
+    const u32 phi0 = __builtin_amdgcn_alignbit(w2, w1, p.near_sh), phi1 = __builtin_amdgcn_alignbit(w3, w2, p.near_sh);   // P >> k
+    const u64 plo = ((u64)(w1 & p.near_mask) << 32) | w0;                                                                 // P mod 2^k
+    const u64 f0 = mad32(phi0, p.delta, plo);                     // < 2^56 + 2^k: no carry out of 64 bits
+    const u64 f1 = mad32(phi1, p.delta, (u64)hi32(f0));           // bits 32.. of F
+    const u32 t = __builtin_amdgcn_alignbit(hi32(f1), lo32(f1), p.near_sh);                                               // F >> k  (< 2^26)
+    const u64 r = ((u64)(lo32(f1) & p.near_mask) << 32) | lo32(f0);
+    return mad32(t, p.delta, r);
 }
 
 // [0, 2q) -> [0, q)
@@ -797,11 +852,14 @@ __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict_
 }
 
 // Inverse (GS) stages on register bits JLO..4 of a layout with register field at bit B.
-template <int LOGN, int HL, int B, int JLO, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0>
+// IN2Q: the inputs are in [0, 2q) instead of canonical (the fused products hand over lazily reduced values); for the classes
+// with 4q of headroom only the first stage's difference changes (x + 2q - y), every later bound is the same.
+template <int LOGN, int HL, int B, int JLO, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0, bool IN2Q = false>
 __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p,
                                          const TwPair* __restrict__ twn)      // twn: &primes[idx].twn[0] -- read where it is used (last round only)
 {
     constexpr InvPolicy<LOGN, HL> POL{};
+    static_assert(!IN2Q || (!Lazy<HL>::EXACT && B == 0 && JLO == 0), "lazy inputs: first round of a class with 4q of headroom only");
     constexpr bool EX = Lazy<HL>::EXACT;
     constexpr bool VEC = (B != Geo<LOGN>::B0);
     using RingT = Ring<LOGN, B, false>;
@@ -824,7 +882,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
         constexpr int beta = B + j;             // index bit of this stage = GS stage number (0 = first)
         constexpr bool last = (beta == LOGN - 1);
         constexpr bool red = (POL.mask >> beta) & 1u;
-        const u64 cq = (u64)POL.cmul[beta] * p.q;
+        const u64 cq = (u64)((IN2Q && beta == 0) ? 2 : POL.cmul[beta]) * p.q;
         TwPair (&Wc)[GROUP] = W[g % DEPTH];
         prio_hook<PSPLIT, PAFTER, g>(t);
         if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1, SCALE>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, twn);
@@ -859,6 +917,19 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
     });
 }
 
+// The pointwise step of the fused products: forward output x in [0, B q) times a word of bhat.  Near-2^k classes with 4q of
+// headroom: fold product, result in [0, 2q) (the inverse's first round then runs with IN2Q); otherwise Algorithm 7 on the
+// canonicalised value, result canonical.
+template <int HL, bool NEAR>
+struct FusedMul {
+    static constexpr bool LAZY = NEAR && !Lazy<HL>::EXACT;
+    __device__ static __forceinline__ u64 mul(u64 x, u64 b, const PrimeDev& p)
+    {
+        if constexpr (LAZY) return mul_fold_near(reduce_2q_near(x, p), b, p);
+        else return barrett_mul(canon_2q(reduce_2q_sel<NEAR>(x, p), p.q), b, p.q, p.mu, p.k);      // poly_arithmetic.cuh:36-66
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // whole transforms on registers.  Entry and exit layout: B0 (coalesced: i = (r << B0) | t).
 // ------------------------------------------------------------------------------------------------
@@ -888,7 +959,7 @@ __device__ __forceinline__ void forward_core(u64 (&v)[32], const TwPair* tw, uns
     fwd_rounds<LOGN, HL, 0, NEAR>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
 }
 
-template <int LOGN, int HL, int RHO, bool NEAR = false>
+template <int LOGN, int HL, int RHO, bool NEAR = false, bool IN2Q = false>
 __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds, const TwPair* twn)
 {
     using G = Geo<LOGN>;
@@ -901,17 +972,17 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             exchange<LOGN, BP, B>(v, lds, t);
             MI355NTT_STAMP(2 * RHO + 2);
         }
-        gs_round<LOGN, HL, B, LOW - B, NEAR>(v, tw, twr, t, p, twn);
+        gs_round<LOGN, HL, B, LOW - B, NEAR, -2, 0, (IN2Q && RHO == 0)>(v, tw, twr, t, p, twn);
         MI355NTT_STAMP(2 * RHO + 3);
-        inv_rounds<LOGN, HL, RHO + 1, NEAR>(v, tw, twr, t, p, lds, twn);
+        inv_rounds<LOGN, HL, RHO + 1, NEAR, IN2Q>(v, tw, twr, t, p, lds, twn);
     }
 }
 
 // bit-reversed values in layout 0 (any representative below 2q... see callers) -> coefficients in layout B0, in [0, TQ*q)
-template <int LOGN, int HL, bool NEAR = false>
+template <int LOGN, int HL, bool NEAR = false, bool IN2Q = false>
 __device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds, const TwPair* twn)
 {
-    inv_rounds<LOGN, HL, 0, NEAR>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds, twn);
+    inv_rounds<LOGN, HL, 0, NEAR, IN2Q>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds, twn);
 }
 
 // [0, TQ*q) -> [0, q).  Near-2^k primes: the 3-instruction fold brings [0, 4q) below 2q, so one compare/select pair

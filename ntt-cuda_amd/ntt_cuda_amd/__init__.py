@@ -79,6 +79,8 @@ _SIGNATURES = {
     "mi355ntt_polymul_batch_shared": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp]),
     "mi355ntt_bfv_encrypt_batch": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_uint, vp]),
     "mi355ntt_bfv_decrypt_batch": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, vp]),
+    "mi355ntt_synth_splitmix": (ctypes.c_int, [vp, vp, ctypes.c_uint, ctypes.c_uint, u64, vp]),
+    "mi355ntt_ctx_last_kernel_clock_mhz": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
     "mi355ntt_raw_cache_clear": (ctypes.c_int, []),
     "mi355ntt_raw_uses_fast_kernels": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
     "mi355ntt_raw_trust_tables": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
@@ -348,6 +350,19 @@ class NTTContext:
         _check(lib().mi355ntt_polymul_batch(self._h, self._p(a, num), self._p(bhat, num), int(num), int(division or self.num_primes),
                                             _stream(stream)), "mi355ntt_polymul_batch")
 
+
+    def synth_splitmix(self, a, num, seed_base=1, division=None, stream=None):
+        """a[y] = splitmix64(seed_base + y) mod q[y % division]: the benchmark's synthetic inputs"""
+        division = self.num_primes if division is None else division
+        _check(lib().mi355ntt_synth_splitmix(self._h, self._p(a, num), int(num), int(division), int(seed_base), _stream(stream)),
+               "mi355ntt_synth_splitmix")
+        return a
+
+    def last_kernel_clock_mhz(self):
+        """shader clock of the last batched n = 2^15 transform launch, sampled inside the kernel (synchronises); 0.0 = none"""
+        v = ctypes.c_double(0.0)
+        _check(lib().mi355ntt_ctx_last_kernel_clock_mhz(self._h, ctypes.byref(v)), "mi355ntt_ctx_last_kernel_clock_mhz")
+        return float(v.value)
 
     def polymul_batch_shared(self, a, bhat, num, division=None, group=0, stream=None):
         """polymul_batch with shared second operands: polynomial y multiplies with bhat[(y // group) * division + y % division]

@@ -3,6 +3,7 @@ parameter helpers agree with the oracle, and argument errors are reported (no GP
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -115,3 +116,20 @@ def test_product_never_imports_oracle():
                     if re.search(r"oracle_py|liboracle|ntt_oracle|orc_", t):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_library_build_rejects_experiment_switches(tmp_path):
+    """The kernels' measurement switches (ablations that produce wrong results, stamps, tuning knobs) are honoured only with
+    -DMI355NTT_LAB (tools/build_kbench.sh): a library translation unit compiled with a stray one must not compile."""
+    src = tmp_path / "probe.hip"
+    src.write_text('#include "ntt_core.cuh"\nint main() { return 0; }\n')
+    inc = ["-I", os.path.join(ROOT, "ntt-cuda_amd", "csrc"), "-I", os.path.join(ROOT, "include")]
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only"] + inc
+    ok = subprocess.run(base + [str(src)], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    for flag in ("-DMI355NTT_ABLATE_EXCHANGE", "-DMI355NTT_STAMPS=1", "-DMI355NTT_PRIO_R1=2", "-DMI355NTT_POLY_SLOT(y)=0"):
+        bad = subprocess.run(base + [flag, str(src)], capture_output=True, text=True)
+        assert bad.returncode != 0 and "MI355NTT_LAB" in bad.stderr, flag
+    lab = subprocess.run(base + ["-DMI355NTT_LAB", "-DMI355NTT_PRIO_R1=2", "-DMI355NTT_PRIO_R2=3", "-DMI355NTT_PRIO_R3=2", "-DMI355NTT_PSPLIT_R3=12",
+                                 "-DMI355NTT_PRIO_R3B=1", str(src)], capture_output=True, text=True)
+    assert lab.returncode == 0, lab.stderr[-2000:]

@@ -1,0 +1,136 @@
+"""GPU, round 3: the measurement helpers of the C ABI (synthetic inputs of the benchmark recipe, the in-kernel clock
+sample), the limits of the batched BFV drivers, the small-batch kernels against the persistent ones, and the two-rank
+shard path on CUDA tensors (gloo, both ranks on the one device)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import params as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def host(native, t):
+    import torch
+    torch.cuda.synchronize()
+    return native.to_host(t)
+
+
+def test_device_synth_is_the_oracle_recipe(native, oracle, gpu):
+    """mi355ntt_synth_splitmix == oracle.synth_batch (polynomial y = splitmix64(seed_base + y) mod q[y % P]):
+    bench.py's inputs are the recipe's, word for word; seeds beyond 32 bits and a division smaller than the prime count too."""
+    import torch
+    n, qs, psis = 32768, P.Q60, P.PSI60
+    ctx = native.NTTContext(n, qs, psis)
+    for num, seed, div in ((9, 1, 4), (5, (1 << 40) + 12345, 4), (6, 77, 2)):
+        a = torch.zeros((num, n), dtype=torch.int64, device="cuda:0")
+        ctx.synth_splitmix(a, num, seed, division=div)
+        assert np.array_equal(host(native, a), oracle.synth_batch(n, num, qs[:div], seed)), (num, seed, div)
+    ctx.close()
+    ctx = native.NTTContext(4096, [P.REF_PARAMS_4096_58BIT[0]], [P.REF_PARAMS_4096_58BIT[1]])
+    a = torch.zeros((3, 4096), dtype=torch.int64, device="cuda:0")
+    ctx.synth_splitmix(a, 3, 1)
+    assert np.array_equal(host(native, a), oracle.synth_batch(4096, 3, [P.REF_PARAMS_4096_58BIT[0]], 1))
+    ctx.close()
+
+
+def test_in_kernel_clock_sample(native, gpu):
+    """the persistent n = 2^15 kernels leave a shader-clock sample (entry / exit of their first workgroup) that the host
+    can read: plausible for gfx950 (0.5 .. 2.6 GHz), absent before the first persistent launch"""
+    import torch
+    n, qs, psis, num = 32768, P.Q60, P.PSI60, 512
+    ctx = native.NTTContext(n, qs, psis)
+    assert ctx.last_kernel_clock_mhz() == 0.0
+    a = torch.zeros((num, n), dtype=torch.int64, device="cuda:0")
+    ctx.synth_splitmix(a, num, 1)
+    a0 = a.clone()
+    for _ in range(5):
+        ctx.forward_batch(a, num)
+    f = ctx.last_kernel_clock_mhz()
+    for _ in range(5):
+        ctx.inverse_batch(a, num)
+    i = ctx.last_kernel_clock_mhz()
+    assert 500.0 < f < 2600.0 and 500.0 < i < 2600.0, (f, i)
+    assert torch.equal(a, a0)
+    ctx.close()
+
+
+def test_bfv_batch_limits_are_checked_before_the_data_is_touched(native, gpu):
+    """count > 65535 (gridDim.z) or count * num_primes >= 2^23 (the key-group field of the fused product): MI355NTT_EUNSUPPORTED
+    and the ciphertext buffer is left as it was (the check used to sit behind the first launch)."""
+    import torch
+    from ntt_cuda_amd import bfv
+    n = 2048
+    q, psi = P.REF_PARAMS[2048][0], P.REF_PARAMS[2048][1]
+    # two copies of a prime are a valid RNS base for this purpose (limits only; nothing is decrypted)
+    qs, psis = [q, P.EDGE_PRIMES[59][0]], [psi, None]
+    psis[1] = next(x for x in (pow(g, (qs[1] - 1) // (2 * n), qs[1]) for g in range(2, 200)) if pow(x, n, qs[1]) == qs[1] - 1)
+    ctx = bfv.BFVContext(n, qs, psis, 1024, P.GAMMA61)
+    lib = native.lib()
+    c = torch.full((64,), 7, dtype=torch.int64, device="cuda:0")
+    key = torch.zeros((2 * 2 * n,), dtype=torch.int64, device="cuda:0")
+    for count in (65536, 1 << 22):
+        rc = lib.mi355ntt_bfv_decrypt_batch(ctx._h, ctypes.c_void_p(c.data_ptr()), ctypes.c_void_p(key.data_ptr()), count, None)
+        assert rc == native.EUNSUPPORTED, (count, rc)
+        rc = lib.mi355ntt_bfv_encrypt_batch(ctx._h, ctypes.c_void_p(c.data_ptr()), ctypes.c_void_p(key.data_ptr()), ctypes.c_void_p(key.data_ptr()),
+                                            ctypes.c_void_p(key.data_ptr()), count, None)
+        assert rc == native.EUNSUPPORTED, (count, rc)
+    torch.cuda.synchronize()
+    assert bool((c == 7).all())
+    ctx.close()
+
+
+@pytest.mark.parametrize("num", [1, 3, 160, 161, 257, 352, 353])
+def test_small_batch_kernels_equal_the_persistent_ones(native, gpu, num):
+    """n = 2^15: the 8-coefficient latency kernels (kernels_lat15.cuh) and the persistent single-pass kernels produce the same
+    words for forward, inverse and the fused product on either side of every switching point of use_latency_path; the path is
+    forced through MI355NTT_LATENCY_PATH_MAX in a child process (the rule is read once per process)."""
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, numpy as np
+import ntt_cuda_amd as ntt, params as P
+num = %d
+ctx = ntt.NTTContext(32768, P.Q60, P.PSI60)
+a = torch.empty((num, 32768), dtype=torch.int64, device="cuda:0"); b = torch.empty_like(a)
+ctx.synth_splitmix(a, num, 11); ctx.synth_splitmix(b, num, 1000003)
+a0 = a.clone()
+ctx.forward_batch(a, num); ctx.forward_batch(b, num)
+h = [hashlib.sha256(ntt.to_host(a).tobytes()).hexdigest()]
+ctx.inverse_batch(a, num)
+assert torch.equal(a, a0)
+ctx.polymul_batch(a, b, num)
+h.append(hashlib.sha256(ntt.to_host(a).tobytes()).hexdigest())
+print(" ".join(h))
+''' % (os.path.join(ROOT, "ntt-cuda_amd"), os.path.join(ROOT, "tests"), num)
+    outs = []
+    for force in ("100000", "0", None):
+        env = dict(os.environ)
+        env.pop("MI355NTT_LATENCY_PATH_MAX", None)
+        if force is not None:
+            env["MI355NTT_LATENCY_PATH_MAX"] = force
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs
+
+
+def test_bench_two_ranks_on_one_gpu_dry_run(native, gpu):
+    """bench.py --gpus 2 --backend gloo: the N > 1 path of the bench on CUDA tensors (spawn_ranks, rank -> device mapping, the
+    barrier / MAX-reduce bracket, shard.scatter_transform_gather through --end-to-end) with both ranks sharing the one GPU.
+    A dry run of the plumbing, not a scaling number."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--batch", "64", "--no-extras", "--no-cpu-baseline", "--end-to-end"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["value"] > 0
+    assert "error" not in out.get("end_to_end", {}), out.get("end_to_end")
+    assert out["end_to_end"]["global_batch"] == 128

@@ -38,7 +38,9 @@ int main(int argc, char** argv)
     u64* a; TwPair* dtw; PrimeDev* dp;
     CK(hipMalloc(&a, (size_t)num * n * 8));
     CK(hipMalloc(&dtw, n * sizeof(TwPair)));
-    CK(hipMalloc(&dp, sizeof(PrimeDev)));
+    CK(hipMalloc(&dp, 2 * sizeof(PrimeDev)));      // [0]: the guard / clock record in front of the array
+    CK(hipMemset(dp, 0, sizeof(PrimeDev)));
+    dp += 1;
     std::vector<u64> h((size_t)num * n);
     u64 x = 88172645463325252ULL;
     for (auto& v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = x % q; }

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r02.json (read by bench.py).
+"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r03.json (read by bench.py).
 
 Compiles ntt-cuda_amd/csrc/kernels_fast_n15.hip to gfx950 assembly, sums the measured steady-state issue cost
 (tools/ubench_issue.hip, profiles/r02_ubench_issue_costs.txt) over the instructions of each kernel's polynomial loop
-and converts to transforms/s: one polynomial per CU at a time, 4 waves per SIMD, 256 CUs, the in-kernel clock the
-chip holds under this load (2.35 GHz, profiles/r02_*: s_memtime / s_memrealtime).  Run here (no GPU needed)."""
+and converts to transforms/s: one polynomial per CU at a time, 4 waves per SIMD, 256 CUs at a NOMINAL 2.35 GHz.  bench.py
+re-prices `cycles_per_polynomial_per_cu` at the shader clock its own timed launches ran at (sampled inside the kernels:
+mi355ntt_ctx_last_kernel_clock_mhz) and at the device's CU count.  Run here (no GPU needed)."""
 import json
 import os
 import re
@@ -62,16 +63,17 @@ def main():
                                os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip"), "-o", out], stderr=subprocess.DEVNULL)
         lines = open(out).read().split('\n')
     res = {}
-    for k, sym in (("k_forward15", "k_forward15ILi4ELb1"), ("k_inverse15", "k_inverse15ILi4ELb1")):
+    for k, sym in (("k_forward15", "k_forward15ILi4ELb1"), ("k_inverse15", "k_inverse15ILi4ELb1"), ("k_polymul15", "k_polymul15ILi4ELb1")):
         cyc, nv, ni = loop_cost(lines, sym)
         per_poly = 4 * cyc                                    # 4 waves share a SIMD
         res[k] = {"valu_issue_cycles_per_wave": cyc, "valu_instructions_per_wave": nv, "loop_instructions": ni,
                   "cycles_per_polynomial_per_cu": per_poly, "transforms_per_s": CUS * CLOCK_HZ / per_poly}
     res["pairs_per_s"] = 1.0 / (1.0 / res["k_forward15"]["transforms_per_s"] + 1.0 / res["k_inverse15"]["transforms_per_s"])
     res["source"] = ("tools/valu_ceiling.py: measured steady-state issue cycles per instruction (profiles/r02_ubench_issue_costs.txt) summed "
-                     "over the polynomial loop of the shipped <HL 4, near-2^k> kernels, 4 waves per SIMD, %d CUs at %.2f GHz in-kernel clock; "
+                     "over the polynomial loop of the shipped <HL 4, near-2^k> kernels, 4 waves per SIMD; transforms_per_s here at a nominal %d CUs x %.2f GHz "
+                     "(bench.py re-prices cycles_per_polynomial_per_cu at the clock sampled inside its timed launches); "
                      "the bare butterfly stream measures 11.1 M transforms/s (profiles/r02_ubench_butterfly_ceiling.txt)" % (CUS, CLOCK_HZ / 1e9))
-    path = os.path.join(ROOT, "profiles", "valu_ceiling_r02.json")
+    path = os.path.join(ROOT, "profiles", "valu_ceiling_r03.json")
     json.dump(res, open(path, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
