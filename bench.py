@@ -293,6 +293,10 @@ def spawn_ranks(args):
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; without it RCCL's (and torch's)
+    # cross-process sharing of device memory fails with "hipIpcGetMemHandle: invalid argument" (environment notes of the
+    # build image).  The image exports it already; it is pinned here so that the ranks inherit it whatever the caller's
+    # shell had, and an explicit setting of the caller's wins.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -618,7 +622,7 @@ def main():
             if world == 1:
                 e2e = lambda: tf(full.clone(), total)
             else:
-                e2e = lambda: shard.scatter_transform_gather(full, total, n, P, tf, chunks=4, src=0, device=dev)
+                e2e = lambda: shard.scatter_transform_gather(full, total, n, P, tf, chunks=4, src=0, device=dev, inplace=True)
             e2e()
             barrier()
             t0 = time.perf_counter()

@@ -95,7 +95,8 @@ def _pieces(count, division, chunks):
     return [(s, c) for s, c in out if c]
 
 
-def scatter_transform_gather(full, num, n, division, transform, chunks=4, src=0, group=None, device=None, dtype=torch.int64):
+def scatter_transform_gather(full, num, n, division, transform, chunks=4, src=0, group=None, device=None, dtype=torch.int64,
+                             inplace=False):
     """End to end from a root-held batch (report 2): root `src` deals the shards out in `chunks` pieces
     per rank, every rank transforms piece k in place with `transform(piece_tensor, count)` while piece k + 1 is arriving
     and piece k - 1 is on its way back, and `src` returns the assembled [num, n] result (other ranks None).
@@ -103,14 +104,18 @@ def scatter_transform_gather(full, num, n, division, transform, chunks=4, src=0,
     Pieces start at multiples of `division`, so `transform` sees polynomial y of a piece with prime y % division -- the
     same call as on the whole batch.  At 8 GPUs the transfers dominate (256 MiB per peer over one xGMI link each way vs
     < 1 ms of transforms), so this is what a caller with a host- or root-resident batch should expect; the compute-only
-    figure is bench.py's default."""
+    figure is bench.py's default.
+
+    inplace=True: the results come back into `full` itself (returned) instead of a second [num, n] tensor -- at BASELINE
+    configs[3] (8192 polynomials, 2 GiB) the root then holds the batch once, not twice.  Safe by construction: the rows of
+    piece k are sent in round k (waited for at the end of that round) and received back in round k + 2."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     plan = {r: shard_range(num, division, r, world) for r in range(world)}
     pieces = {r: [(plan[r][0] + s, c) for s, c in _pieces(plan[r][1], division, chunks)] if plan[r][1] else [] for r in range(world)}
     depth = max(len(p) for p in pieces.values()) if pieces else 0
     if rank == src:
         full = full.reshape(num, n)
-        out = torch.empty_like(full)
+        out = full if inplace else torch.empty_like(full)
         for k in range(depth + 2):
             ops = []
             for r in range(world):                                   # piece k goes out, piece k - 2 comes back
@@ -126,7 +131,8 @@ def scatter_transform_gather(full, num, n, division, transform, chunks=4, src=0,
             if 0 <= k - 1 < len(pieces[src]):                        # the root's own piece k - 1 meanwhile
                 s, c = pieces[src][k - 1]
                 piece = out[s:s + c]                                   # contiguous rows of the result: transform in place there
-                piece.copy_(full[s:s + c])
+                if not inplace:
+                    piece.copy_(full[s:s + c])
                 transform(piece, c)
             for q in reqs:
                 q.wait()

@@ -77,7 +77,7 @@ def test_scatter_transform_gather_world2(tmp_path, num):
     assert np.load(out)[0] == 1
 
 
-def _worker_e2e(rank, world, port, num, n, chunks, out):
+def _worker_e2e(rank, world, port, num, n, chunks, out, inplace=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
@@ -99,10 +99,12 @@ def _worker_e2e(rank, world, port, num, n, chunks, out):
         res = oracle.forward_batch(piece.numpy().view(np.uint64), prm, division=len(qs)).reshape(count, n)
         piece.copy_(torch.from_numpy(res.view(np.int64)))
 
-    got = shard.scatter_transform_gather(full, num, n, len(qs), transform, chunks=chunks, src=0)
+    keep = full.clone() if rank == 0 else None
+    got = shard.scatter_transform_gather(full, num, n, len(qs), transform, chunks=chunks, src=0, inplace=inplace)
     assert sum(calls) == shard.shard_range(num, len(qs), rank, world)[1]
     if rank == 0:
-        want = oracle.forward_batch(full.numpy().view(np.uint64), prm, division=len(qs)).reshape(num, n)
+        assert (got.data_ptr() == full.data_ptr()) == inplace          # in place: the root holds the batch once
+        want = oracle.forward_batch(keep.numpy().view(np.uint64), prm, division=len(qs)).reshape(num, n)
         np.save(out, np.array([int(np.array_equal(got.numpy().view(np.uint64), want))]))
     dist.destroy_process_group()
 
@@ -113,6 +115,14 @@ def test_pipelined_scatter_transform_gather_world2(tmp_path, num, chunks):
     whole batch returns, also for ragged batches and when a rank gets nothing"""
     out = str(tmp_path / "ok.npy")
     mp.spawn(_worker_e2e, args=(2, _free_port(), num, 4096, chunks, out), nprocs=2, join=True)
+    assert np.load(out)[0] == 1
+
+
+@pytest.mark.parametrize("num,chunks", [(24, 3), (7, 4)])
+def test_pipelined_scatter_transform_gather_in_place_world2(tmp_path, num, chunks):
+    """inplace=True: the results return into the root's own batch tensor (no second [num, n] buffer at the root)"""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker_e2e, args=(2, _free_port(), num, 4096, chunks, out, True), nprocs=2, join=True)
     assert np.load(out)[0] == 1
 
 
