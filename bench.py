@@ -379,19 +379,20 @@ def main():
     # ---- per-kernel launch durations: HIP events on the launch stream (torch's current stream) around K back-to-back
     # launches of each kernel (events between every launch of the step loop would serialise the queue and inflate both)
     def kernel_ms(fn):
+        """(ms per launch, shader clock in MHz right behind the same launches: a clock probe -- one wave counting s_memtime
+        cycles over 20 us of s_memrealtime -- enqueued behind the closing event)"""
         b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         b0.record()
         for _ in range(args.steps):
             fn()
         b1.record()
+        ctx.clock_probe()
         torch.cuda.synchronize()
-        return b0.elapsed_time(b1) / args.steps
+        return b0.elapsed_time(b1) / args.steps, ctx.probed_clock_mhz()
 
-    fwd_ms = kernel_ms(lambda: ctx.forward_batch(a, batch))
-    fwd_clock_mhz = ctx.last_kernel_clock_mhz()         # sampled inside the last k_forward15 launch (s_memtime / s_memrealtime)
-    inv_ms = kernel_ms(lambda: ctx.inverse_batch(a, batch))
-    inv_clock_mhz = ctx.last_kernel_clock_mhz()
+    fwd_ms, fwd_clock_mhz = kernel_ms(lambda: ctx.forward_batch(a, batch))
+    inv_ms, inv_clock_mhz = kernel_ms(lambda: ctx.inverse_batch(a, batch))
     # `a` has now seen K forwards then K inverses: still a valid round trip
     assert torch.equal(a, a0)
 
@@ -471,7 +472,7 @@ def main():
                      "valu_ceiling_pairs_per_s": valu_pairs,
                      "pair_frac_of_valu_ceiling": (pairs_per_s / world / valu_pairs) if valu_pairs else None,
                      "in_kernel_clock_mhz": {"k_forward15": fwd_clock_mhz, "k_inverse15": inv_clock_mhz,
-                                             "how": "first workgroup of the last timed launch: s_memtime (shader cycles) over s_memrealtime (100 MHz) between kernel entry and exit"},
+                                             "how": "a clock probe (one wave: s_memtime shader cycles counted over 20 us of the 100 MHz s_memrealtime) enqueued right behind the K back-to-back launches the kernel time is taken from"},
                      "compute_units": cus,
                      "valu_ceiling_source": "profiles/valu_ceiling_r03.json (tools/valu_ceiling.py: measured issue cycles per instruction summed over the shipped "
                                             "kernels' polynomial loops) x compute_units x in_kernel_clock_mhz of this run"},
@@ -561,7 +562,6 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         mulN_ms = e0.elapsed_time(e1) / 40
-        mul_clock = ctx.last_kernel_clock_mhz()         # (k_polymul15 does not sample; this is the last transform's figure)
         polymul = {"batch": batch, "ms_per_launch": mulN_ms, "products_per_s": batch / (mulN_ms * 1e-3),
                    "polymul_frac": batch * 1310720 / (mulN_ms * 1e-3) / HBM_PEAK,
                    "polymul_frac_fused_bytes": batch * 786432 / (mulN_ms * 1e-3) / HBM_PEAK,

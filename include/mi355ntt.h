@@ -106,6 +106,13 @@ const mi355ntt_u64* mi355ntt_ctx_psiinv_tables(const mi355ntt_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------
  * Transforms on a context
+ *
+ * Stream capture.  Every launching entry point on a context or a BFV object (transforms, pointwise and fused products, the
+ * BFV drivers single and batched, the samplers) only enqueues kernels on `stream`: no allocation, no synchronisation, no
+ * host read, no memcpy after mi355ntt_ctx_create / mi355ntt_bfv_create.  They may therefore be called between
+ * hipStreamBeginCapture and hipStreamEndCapture and the resulting hipGraph replayed (tools/lat_bench.cpp does, and checks
+ * the results).  Not capture-safe: context / BFV creation and destruction, mi355ntt_ctx_probed_clock_mhz, and the
+ * FIRST call of a raw-parameter entry point with a given table (it derives and caches a context: see below).
  * ---------------------------------------------------------------------------------------------- */
 /* forwardNTT (ntt_60bit.cuh:314-348): one polynomial, prime prime_idx */
 int mi355ntt_forward(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream stream);
@@ -152,9 +159,12 @@ int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, co
  * x += 0x9E3779B97F4A7C15 per value, value = mix(x) mod q). */
 int mi355ntt_synth_splitmix(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned num, unsigned division,
                             mi355ntt_u64 seed_base, mi355ntt_stream stream);
-/* Shader clock (MHz) the context's last batched n = 2^15 transform launch ran at, sampled inside the kernel (first workgroup:
- * shader-cycle counter against the 100 MHz constant clock at entry and exit).  Synchronises the device.  0 = no sample. */
-int mi355ntt_ctx_last_kernel_clock_mhz(const mi355ntt_ctx* ctx, double* mhz);
+/* Clock probe.  mi355ntt_ctx_clock_probe enqueues a one-wave kernel on `stream` that counts shader cycles over 20 us of the
+ * 100 MHz constant clock; mi355ntt_ctx_probed_clock_mhz returns the last probe's result in MHz: the shader clock the launches
+ * enqueued in front of the probe left the chip at (bench.py prices its VALU ceiling with it; the power management moves the clock
+ * over milliseconds).  The second call synchronises the device.  0 until a probe has run. */
+int mi355ntt_ctx_clock_probe(const mi355ntt_ctx* ctx, mi355ntt_stream stream);
+int mi355ntt_ctx_probed_clock_mhz(const mi355ntt_ctx* ctx, double* mhz);
 
 /* ------------------------------------------------------------------------------------------------
  * Raw-parameter entry points: signature-compatible with the reference (the caller supplies q, mu, bit_length and

@@ -404,20 +404,23 @@ int mi355ntt_synth_splitmix(const mi355ntt_ctx* c, mi355ntt_u64* d_a, unsigned n
     return MI355NTT_OK;
 }
 
-/* Shader clock of the context's last n = 2^15 persistent transform launch (k_forward15 / k_inverse15), measured by the kernel
- * itself: its first workgroup stores s_memtime (shader cycles) and s_memrealtime (100 MHz) when it enters and when it leaves
- * (kernels_fast_impl.cuh, kernel_clock_mark).  Blocks until the device has finished (a host read).  *mhz = 0 when no such
- * launch has run on this context. */
-int mi355ntt_ctx_last_kernel_clock_mhz(const mi355ntt_ctx* c, double* mhz)
+/* Clock probe: mi355ntt_ctx_clock_probe enqueues a one-wave kernel on `stream` that counts shader cycles (s_memtime) over 20 us
+ * of the 100 MHz constant clock (s_memrealtime); mi355ntt_ctx_probed_clock_mhz returns the last probe's result -- the shader clock
+ * the work enqueued in front of the probe left the chip at.  The second call synchronises the device (a host read).  *mhz = 0
+ * until a probe has run. */
+int mi355ntt_ctx_clock_probe(const mi355ntt_ctx* c, mi355ntt_stream s)
+{
+    if (!c) return MI355NTT_EINVAL;
+    ON_CTX_DEVICE(c);
+    HIP_TRY(fast_clock_probe(c->fast, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+
+int mi355ntt_ctx_probed_clock_mhz(const mi355ntt_ctx* c, double* mhz)
 {
     if (!c || !mhz) return MI355NTT_EINVAL;
-    *mhz = 0.0;
-    if (!c->fast.d_primes_alloc) return MI355NTT_OK;
     ON_CTX_DEVICE(c);
-    unsigned long long w[4] = {0, 0, 0, 0};
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(w, static_cast<const char*>(c->fast.d_primes_alloc) + 16, sizeof(w), hipMemcpyDeviceToHost));
-    if (w[3] > w[1] && w[2] > w[0]) *mhz = (double)(w[2] - w[0]) / (double)(w[3] - w[1]) * 100.0;
+    HIP_TRY(fast_probed_clock_mhz(c->fast, mhz));
     return MI355NTT_OK;
 }
 

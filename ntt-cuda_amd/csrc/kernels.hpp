@@ -84,6 +84,9 @@ struct FastTables {
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
                               const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv);
 void fast_tables_destroy(FastTables* t);
+// measurement helper: a stream-ordered clock probe (20 us) and the shader clock it measured (the read synchronises)
+hipError_t fast_clock_probe(const FastTables& t, hipStream_t s);
+hipError_t fast_probed_clock_mhz(const FastTables& t, double* mhz);
 // polynomial y of the batch uses prime (prime_base + y % division)
 hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);
 hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);

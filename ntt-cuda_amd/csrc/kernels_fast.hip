@@ -36,6 +36,27 @@ k_pointwise(u64* __restrict__ c, const u64* __restrict__ a, const u64* __restric
     }
 }
 
+// Clock probe (measurement helper): one wave reads the shader-cycle counter (s_memtime) and the 100 MHz constant clock
+// (s_memrealtime), spins until 20 us of constant clock have passed and reads both again; the differences go into the guard record
+// in front of the PrimeDev array (bytes 16..31; bytes 0..7 are the guard words of the checked raw calls).  Enqueued right behind
+// a run of launches it reports the shader clock that run left the chip at (the power management moves the clock over
+// milliseconds, the probe takes 20 us).  Both readings come from the same wave: the cycle counters of different XCDs are not
+// synchronised, so two one-shot probes cannot be subtracted.  A kernel of its own because marks inside k_forward15 /
+// k_inverse15 cost the general-prime instantiations their last free VGPRs (scratch again; measured in round 3).
+__global__ void __launch_bounds__(64) k_clock_probe(unsigned long long* __restrict__ rec)
+{
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+    do {
+        __builtin_amdgcn_s_sleep(8);
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+    } while (r1 - r0 < 2000);
+    if (threadIdx.x == 0) {
+        rec[2] = t1 - t0;
+        rec[3] = r1 - r0;
+    }
+}
+
 ModSet shifted(const ModSet& m, unsigned base, unsigned division)
 {
     ModSet r;
@@ -167,6 +188,25 @@ void fast_tables_destroy(FastTables* t)
     t->d_primes_alloc = nullptr;
     t->d_fwd = t->d_inv = nullptr;
     t->d_primes = nullptr;
+}
+
+hipError_t fast_clock_probe(const FastTables& t, hipStream_t s)
+{
+    if (!t.d_primes_alloc) return hipErrorInvalidValue;
+    k_clock_probe<<<1, 64, 0, s>>>(static_cast<unsigned long long*>(t.d_primes_alloc));
+    return hipGetLastError();
+}
+
+hipError_t fast_probed_clock_mhz(const FastTables& t, double* mhz)
+{
+    *mhz = 0.0;
+    if (!t.d_primes_alloc) return hipSuccess;
+    unsigned long long w[2] = {0, 0};                // {shader cycles, 100 MHz ticks} of the last probe
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    if ((e = hipMemcpy(w, static_cast<const char*>(t.d_primes_alloc) + 16, sizeof(w), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    if (w[1] != 0) *mhz = (double)w[0] / (double)w[1] * 100.0;
+    return hipSuccess;
 }
 
 hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)

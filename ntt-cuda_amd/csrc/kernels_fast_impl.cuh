@@ -71,11 +71,15 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned t = threadIdx.x;
+    // thread-derived values are rebuilt where they are used (wave index in an SGPR, lane index from v_mbcnt), as in the
+    // n = 2^15 kernels: one VGPR kept live across the polynomial loop was a spill in several instantiations
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+s"(wave_s));
+    auto tid = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
     MI355NTT_STAMP(15);
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)y * G::N, t);
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)y * G::N, tid());
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -87,21 +91,21 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         const TwPair* twp = tw + (size_t)idx * G::N;
         u64* poly = a + (size_t)y * G::N;
         MI355NTT_STAMP(0);
-        forward_core<LOGN, HL, NEAR>(v, twp, t, p, lds);
+        forward_core<LOGN, HL, NEAR>(v, twp, tid, p, lds);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMP(6);
 #if MI355NTT_SMALL_ROW_STAGING
         // layout 0 (32 consecutive words per thread) leaves through the wave's own 8 KiB of the image with 16-byte stores
         // (as on n = 2^15) instead of a workgroup-wide layout exchange and 8-byte stores
         __syncthreads();        // every wave has read the last exchange: the image is free
-        wave_store_rows(v, lds + (t >> 6) * 1024u, make_rsrc(poly, G::N * 8u), (t >> 6) * 16384u, 0u);
+        wave_store_rows(v, lds + wave_s * 1024u, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
         MI355NTT_STAMP(7);
 #else
-        exchange<LOGN, 0, G::B0>(v, lds, t);
+        exchange<LOGN, 0, G::B0>(v, lds, tid());
         MI355NTT_STAMP(7);
-        store_coalesced<LOGN>(v, poly, t);
+        store_coalesced<LOGN>(v, poly, tid());
 #endif
-        if (y + gridDim.x < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        if (y + gridDim.x < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(y + gridDim.x) * G::N, tid());
         MI355NTT_STAMP(8);
         __syncthreads();        // the next polynomial's first exchange reuses the LDS image
     }
@@ -116,17 +120,19 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    const unsigned t = threadIdx.x;
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (thread-derived values: see k_forward)
+    asm volatile("" : "+s"(wave_s));
+    auto tid = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
     MI355NTT_STAMP(15);
 #if MI355NTT_SMALL_ROW_STAGING
     // rows (16-byte loads) through the wave's own 8 KiB of the image straight into layout 0: no layout exchange
-    wave_load_rows(v, lds + (t >> 6) * 1024u, make_rsrc(a + (size_t)y * G::N, G::N * 8u), (t >> 6) * 16384u, 0u);
+    wave_load_rows(v, lds + wave_s * 1024u, make_rsrc(a + (size_t)y * G::N + wave_s * 2048u, 16384u), 0u, 0u);
     __syncthreads();        // every wave has left its staging slice: the first exchange writes the workgroup-wide image over them
                             // (later iterations are covered by the barrier at the loop's end)
 #else
-    load_coalesced<LOGN>(v, a + (size_t)y * G::N, t);
+    load_coalesced<LOGN>(v, a + (size_t)y * G::N, tid());
 #endif
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
@@ -140,19 +146,19 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         u64* poly = a + (size_t)y * G::N;
         MI355NTT_STAMP(0);
 #if !MI355NTT_SMALL_ROW_STAGING
-        exchange<LOGN, G::B0, 0>(v, lds, t);
+        exchange<LOGN, G::B0, 0>(v, lds, tid());
 #endif
         MI355NTT_STAMP(1);
-        inverse_core<LOGN, HL, NEAR>(v, twp, t, p, lds, primes[idx].twn);
+        inverse_core<LOGN, HL, NEAR>(v, twp, tid, p, lds, primes[idx].twn);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP(8);
-        store_coalesced<LOGN>(v, poly, t);
+        store_coalesced<LOGN>(v, poly, tid());
 #if MI355NTT_SMALL_ROW_STAGING
         __syncthreads();        // every wave has read the last exchange: the image is free for the row staging
         if (y + gridDim.x < num)
-            wave_load_rows(v, lds + (t >> 6) * 1024u, make_rsrc(a + (size_t)(y + gridDim.x) * G::N, G::N * 8u), (t >> 6) * 16384u, 0u);
+            wave_load_rows(v, lds + wave_s * 1024u, make_rsrc(a + (size_t)(y + gridDim.x) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
 #else
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, t);
+        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, tid());
 #endif
         MI355NTT_STAMP(9);
         __syncthreads();
@@ -278,7 +284,6 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
-    kernel_clock_mark(primes - 1, 0);
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_FWD, MI355NTT_STAGGER_FWD_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
@@ -325,7 +330,6 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
     }
-    kernel_clock_mark(primes - 1, 1);
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }
@@ -348,7 +352,6 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64 v[32];
     unsigned y = blockIdx.x;
     if (y >= num) return;
-    kernel_clock_mark(primes - 1, 0);
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
@@ -392,7 +395,6 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
     }
-    kernel_clock_mark(primes - 1, 1);
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
 }
@@ -518,27 +520,30 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
     const unsigned y = blockIdx.x;
-    const unsigned idx = y % division;
+    const unsigned idx = __builtin_amdgcn_readfirstlane(y % division);      // (uniform: keeps the table and constant addresses in SGPRs)
     const PrimeDev p = primes[idx];
     u64* poly = a + (size_t)y * G::N;
     const u64* bp = bhat + (size_t)sb.index(y, idx, division) * G::N;
-    const unsigned t = threadIdx.x;
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (thread-derived values: see k_forward)
+    asm volatile("" : "+s"(wave_s));
+    auto tid = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly, t);
-    forward_core<LOGN, HL, NEAR>(v, twf + (size_t)idx * G::N, t, p, lds);
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly, tid());
+    forward_core<LOGN, HL, NEAR>(v, twf + (size_t)idx * G::N, tid, p, lds);
     // layout 0: this thread holds NTT values 32t .. 32t+31; the inverse starts from the same layout
     const BufRsrc brs = make_rsrc(bp, G::N * 8u);
+    const unsigned boff = tid() * 256u;
 #pragma unroll
     for (int r = 0; r < 32; r += 2) {
-        const TwPair bb = buf_load_tw(brs, t * 256u, (unsigned)r * 8u);      // two consecutive words of bhat
+        const TwPair bb = buf_load_tw(brs, boff, (unsigned)r * 8u);      // two consecutive words of bhat
         v[r] = FusedMul<HL, NEAR>::mul(v[r], bb.w, p);
         v[r + 1] = FusedMul<HL, NEAR>::mul(v[r + 1], bb.wp, p);
         if ((r & 6) == 6) __builtin_amdgcn_sched_barrier(0);
     }
-    inverse_core<LOGN, HL, NEAR, FusedMul<HL, NEAR>::LAZY>(v, twi + (size_t)idx * G::N, t, p, lds, primes[idx].twn);
+    inverse_core<LOGN, HL, NEAR, FusedMul<HL, NEAR>::LAZY>(v, twi + (size_t)idx * G::N, tid, p, lds, primes[idx].twn);
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL, NEAR>(v[r], p);
-    store_coalesced<LOGN>(v, poly, t);
+    store_coalesced<LOGN>(v, poly, tid());
 }
 
 // Workgroups that can be resident at once: 256 CUs x (what 128 VGPRs/thread, the LDS image and 32 waves/CU admit).

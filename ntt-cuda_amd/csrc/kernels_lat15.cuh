@@ -213,7 +213,7 @@ k_lat15_fwd_a(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev
     __shared__ u64 lds[4096];
     const unsigned y = blockIdx.x >> 3, g = blockIdx.x & 7u;
     const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const unsigned idx = prime_base + y % division;
+    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * 32768u;
     const BufRsrc twr = make_rsrc(twp, 32768u * 16u), prs = make_rsrc(a + (size_t)y * 32768u, 32768u * 8u);
@@ -234,7 +234,7 @@ k_lat15_inv_a(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev
     __shared__ u64 lds[4096];
     const unsigned y = blockIdx.x >> 3, g = blockIdx.x & 7u;
     const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const unsigned idx = prime_base + y % division;
+    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * 32768u;
     const BufRsrc twr = make_rsrc(twp, 32768u * 16u), prs = make_rsrc(a + (size_t)y * 32768u, 32768u * 8u);
@@ -308,7 +308,7 @@ k_lat15_fwd_b(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev
     if (guard_says_skip(primes, prime_base)) return;
     __shared__ u64 slice[LAT_SLICE_WORDS];
     const unsigned y = blockIdx.x >> 6, c = blockIdx.x & 63u, lane = threadIdx.x;
-    const unsigned idx = prime_base + y % division;
+    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * 32768u;
     const BufRsrc twr = make_rsrc(twp, 32768u * 16u), prs = make_rsrc(a + (size_t)y * 32768u, 32768u * 8u);
@@ -326,7 +326,7 @@ k_lat15_inv_b(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev
     if (guard_says_skip(primes, prime_base)) return;
     __shared__ u64 slice[LAT_SLICE_WORDS];
     const unsigned y = blockIdx.x >> 6, c = blockIdx.x & 63u, lane = threadIdx.x;
-    const unsigned idx = prime_base + y % division;
+    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * 32768u;
     const BufRsrc twr = make_rsrc(twp, 32768u * 16u), prs = make_rsrc(a + (size_t)y * 32768u, 32768u * 8u);
@@ -346,7 +346,7 @@ k_lat15_mul_b(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* _
     const SharedB sb(division);
     __shared__ u64 slice[LAT_SLICE_WORDS];
     const unsigned y = blockIdx.x >> 6, c = blockIdx.x & 63u, lane = threadIdx.x;
-    const unsigned idx = y % division;
+    const unsigned idx = __builtin_amdgcn_readfirstlane(y % division);
     const PrimeDev p = primes[idx];
     const TwPair* tf = twf + (size_t)idx * 32768u;
     const TwPair* ti = twi + (size_t)idx * 32768u;

@@ -108,22 +108,6 @@ constexpr unsigned kWgLogCap = 1u << 16;
 #define MI355NTT_STAMP_FLUSH
 #endif
 
-// In-kernel clock sample of the persistent n = 2^15 kernels: the first lane of workgroup 0 stores the shader-cycle counter and
-// the 100 MHz constant clock at entry (slot 0) and at exit (slot 1) into the guard record in front of the PrimeDev array
-// (bytes 16..47; bytes 0..7 are the guard words of the checked raw calls).  mi355ntt_ctx_last_kernel_clock_mhz reads them:
-// bench.py prices its VALU ceiling at the clock the timed launches actually ran at.  Cost: two scalar clock reads and one
-// 16-byte store per launch and mark.
-__device__ __forceinline__ void kernel_clock_mark(const void* primes_base, unsigned slot)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long tm, rt;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm), "=s"(rt) :: "memory");
-        unsigned long long* c = reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(primes_base)) + 2 + 2 * slot;
-        c[0] = tm;
-        c[1] = rt;
-    }
-}
-
 struct TwPair {       // {w, floor(w * 2^64 / q)}
     u64 w, wp;
 };
@@ -452,6 +436,21 @@ __host__ __device__ constexpr unsigned drop_bit(unsigned i)
 }
 __host__ __device__ constexpr unsigned slot_of(unsigned ip) { return (ip >> 5) * 34u + (ip & 31u); }
 
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Two adjacent 64-bit words from two INDEPENDENT register pairs (ds_write2_b64, offsets in units of 8 bytes).  A 16-byte
+// store of (v[r], v[r+1]) as one ds_write_b128 needs the four VGPRs consecutive; the allocator cannot arrange that for all
+// sixteen pairs of a round's outputs and assembles the tuples with copies -- in the general-prime kernels with spills.
+// Inline asm: callers fence with wave_lds_fence() / a barrier before the words are read (the compiler's own waitcnt
+// insertion does not see these stores).
+template <int OFF8>
+__device__ __forceinline__ void lds_write2_u64(u64* addr, u64 a, u64 b)
+{
+    static_assert(OFF8 >= 0 && OFF8 + 1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
+    const u32 la = (u32)reinterpret_cast<uintptr_t>(addr);      // LDS addresses are 32-bit (the low half of the flat address)
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(la), "v"(a), "v"(b), "n"(OFF8), "n"(OFF8 + 1) : "memory");
+}
+
 // Transposition through LDS: registers hold layout BO on entry, layout BN on exit.
 // Two-phase case: the phase bit is the TOP REGISTER BIT OF THE READER layout, so every thread reads half of its
 // registers in each phase (no divergent register definitions); writers take part in the phase their element
@@ -486,7 +485,9 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
                 constexpr int r = decltype(rc)::value * (BO == 0 ? 2 : 1);
                 if constexpr (!W_REG_SPLIT || ((((unsigned)r << BO) >> (PB < 0 ? 0 : PB)) & 1u) == ph) {
                     constexpr unsigned off = slot_of(drop_bit<PB>((unsigned)r << BO));
-                    if constexpr (BO == 0)
+                    if constexpr (BO == 0 && (off % SEG) + 1 < 256)
+                        lds_write2_u64<off % SEG>(wb[off / SEG], v[r], v[r + 1]);       // (pair store without a register tuple)
+                    else if constexpr (BO == 0)
                         *reinterpret_cast<ulonglong2*>(wb[off / SEG] + off % SEG) = make_ulonglong2(v[r], v[r + 1]);
                     else
                         wb[off / SEG][off % SEG] = v[r];
@@ -521,21 +522,6 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
 // LDS and VALU phases overlap.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned WAVE_SLICE_WORDS = 1152;     // 2 half-waves x 32 rows x 18 words = 9216 B per wave (16 slices = 144 KiB)
-
-__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// Two adjacent 64-bit words from two INDEPENDENT register pairs (ds_write2_b64, offsets in units of 8 bytes).  A 16-byte
-// store of (v[r], v[r+1]) as one ds_write_b128 needs the four VGPRs consecutive; the allocator cannot arrange that for all
-// sixteen pairs of a round's outputs and assembles the tuples with copies -- in the general-prime kernels with spills.
-// Inline asm: callers fence with wave_lds_fence() / a barrier before the words are read (the compiler's own waitcnt
-// insertion does not see these stores).
-template <int OFF8>
-__device__ __forceinline__ void lds_write2_u64(u64* addr, u64 a, u64 b)
-{
-    static_assert(OFF8 >= 0 && OFF8 + 1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
-    const u32 la = (u32)reinterpret_cast<uintptr_t>(addr);      // LDS addresses are 32-bit (the low half of the flat address)
-    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(la), "v"(a), "v"(b), "n"(OFF8), "n"(OFF8 + 1) : "memory");
-}
 
 // layout 5 -> layout 0.  Per half-wave (32 lanes) this is a 32x32 transpose: lane (h, c) holds M[r][c] in register r
 // and ends with row (its own c): M[c][0..31].  Two steps of 16 COLUMNS each: the lanes owning those columns store
@@ -933,8 +919,10 @@ struct FusedMul {
 // ------------------------------------------------------------------------------------------------
 // whole transforms on registers.  Entry and exit layout: B0 (coalesced: i = (r << B0) | t).
 // ------------------------------------------------------------------------------------------------
-template <int LOGN, int HL, int RHO, bool NEAR = false>
-__device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds)
+// TID: callable returning the thread index -- rebuilt at every use (wave index from an SGPR, lane index from v_mbcnt) instead of
+// one VGPR kept live across the whole transform
+template <int LOGN, int HL, int RHO, bool NEAR = false, class TID>
+__device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, TID t, const PrimeDev& p, u64* lds)
 {
     using G = Geo<LOGN>;
     if constexpr (RHO < G::NR) {
@@ -943,24 +931,24 @@ __device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRs
         if constexpr (RHO > 0) {
             constexpr int TOPP = LOGN - 1 - 5 * (RHO - 1);
             constexpr int BP = TOPP - 4 > 0 ? TOPP - 4 : 0;
-            exchange<LOGN, BP, B>(v, lds, t);
+            exchange<LOGN, BP, B>(v, lds, t());
             MI355NTT_STAMP(2 * RHO);
         }
-        ct_round<LOGN, HL, B, TOP - B, NEAR>(v, tw, twr, t, p);
+        ct_round<LOGN, HL, B, TOP - B, NEAR>(v, tw, twr, t(), p);
         MI355NTT_STAMP(2 * RHO + 1);
         fwd_rounds<LOGN, HL, RHO + 1, NEAR>(v, tw, twr, t, p, lds);
     }
 }
 
 // natural-order coefficients in (layout B0, canonical) -> bit-reversed NTT values, left in layout 0, in [0, B*q)
-template <int LOGN, int HL, bool NEAR = false>
-__device__ __forceinline__ void forward_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds)
+template <int LOGN, int HL, bool NEAR = false, class TID>
+__device__ __forceinline__ void forward_core(u64 (&v)[32], const TwPair* tw, TID t, const PrimeDev& p, u64* lds)
 {
     fwd_rounds<LOGN, HL, 0, NEAR>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds);
 }
 
-template <int LOGN, int HL, int RHO, bool NEAR = false, bool IN2Q = false>
-__device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, unsigned t, const PrimeDev& p, u64* lds, const TwPair* twn)
+template <int LOGN, int HL, int RHO, bool NEAR = false, bool IN2Q = false, class TID>
+__device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRsrc twr, TID t, const PrimeDev& p, u64* lds, const TwPair* twn)
 {
     using G = Geo<LOGN>;
     if constexpr (RHO < G::NR) {
@@ -969,18 +957,18 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRs
         if constexpr (RHO > 0) {
             constexpr int LOWP = 5 * (RHO - 1);
             constexpr int BP = LOWP < G::B0 ? LOWP : G::B0;
-            exchange<LOGN, BP, B>(v, lds, t);
+            exchange<LOGN, BP, B>(v, lds, t());
             MI355NTT_STAMP(2 * RHO + 2);
         }
-        gs_round<LOGN, HL, B, LOW - B, NEAR, -2, 0, (IN2Q && RHO == 0)>(v, tw, twr, t, p, twn);
+        gs_round<LOGN, HL, B, LOW - B, NEAR, -2, 0, (IN2Q && RHO == 0)>(v, tw, twr, t(), p, twn);
         MI355NTT_STAMP(2 * RHO + 3);
         inv_rounds<LOGN, HL, RHO + 1, NEAR, IN2Q>(v, tw, twr, t, p, lds, twn);
     }
 }
 
 // bit-reversed values in layout 0 (any representative below 2q... see callers) -> coefficients in layout B0, in [0, TQ*q)
-template <int LOGN, int HL, bool NEAR = false, bool IN2Q = false>
-__device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, unsigned t, const PrimeDev& p, u64* lds, const TwPair* twn)
+template <int LOGN, int HL, bool NEAR = false, bool IN2Q = false, class TID>
+__device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, TID t, const PrimeDev& p, u64* lds, const TwPair* twn)
 {
     inv_rounds<LOGN, HL, 0, NEAR, IN2Q>(v, tw, make_rsrc(tw, Geo<LOGN>::N * 16u), t, p, lds, twn);
 }

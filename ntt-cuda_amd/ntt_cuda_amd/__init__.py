@@ -80,7 +80,8 @@ _SIGNATURES = {
     "mi355ntt_bfv_encrypt_batch": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_uint, vp]),
     "mi355ntt_bfv_decrypt_batch": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, vp]),
     "mi355ntt_synth_splitmix": (ctypes.c_int, [vp, vp, ctypes.c_uint, ctypes.c_uint, u64, vp]),
-    "mi355ntt_ctx_last_kernel_clock_mhz": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
+    "mi355ntt_ctx_clock_probe": (ctypes.c_int, [vp, vp]),
+    "mi355ntt_ctx_probed_clock_mhz": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
     "mi355ntt_raw_cache_clear": (ctypes.c_int, []),
     "mi355ntt_raw_uses_fast_kernels": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
     "mi355ntt_raw_trust_tables": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
@@ -358,10 +359,14 @@ class NTTContext:
                "mi355ntt_synth_splitmix")
         return a
 
-    def last_kernel_clock_mhz(self):
-        """shader clock of the last batched n = 2^15 transform launch, sampled inside the kernel (synchronises); 0.0 = none"""
+    def clock_probe(self, stream=None):
+        """enqueue a clock probe on the stream: shader cycles counted over 20 us of the 100 MHz clock"""
+        _check(lib().mi355ntt_ctx_clock_probe(self._h, _stream(stream)), "mi355ntt_ctx_clock_probe")
+
+    def probed_clock_mhz(self):
+        """shader clock measured by the last probe: what the launches enqueued in front of it left the chip at (synchronises); 0.0 = none"""
         v = ctypes.c_double(0.0)
-        _check(lib().mi355ntt_ctx_last_kernel_clock_mhz(self._h, ctypes.byref(v)), "mi355ntt_ctx_last_kernel_clock_mhz")
+        _check(lib().mi355ntt_ctx_probed_clock_mhz(self._h, ctypes.byref(v)), "mi355ntt_ctx_probed_clock_mhz")
         return float(v.value)
 
     def polymul_batch_shared(self, a, bhat, num, division=None, group=0, stream=None):

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -133,3 +134,15 @@ def test_library_build_rejects_experiment_switches(tmp_path):
     lab = subprocess.run(base + ["-DMI355NTT_LAB", "-DMI355NTT_PRIO_R1=2", "-DMI355NTT_PRIO_R2=3", "-DMI355NTT_PRIO_R3=2", "-DMI355NTT_PSPLIT_R3=12",
                                  "-DMI355NTT_PRIO_R3B=1", str(src)], capture_output=True, text=True)
     assert lab.returncode == 0, lab.stderr[-2000:]
+
+
+def test_n15_kernels_use_no_scratch():
+    """Every n = 2^15 kernel instantiation (18 persistent + 30 small-batch: headroom class x near / general prime) fits its
+    128-VGPR budget without scratch memory (compiler remarks; tools/kernel_resources.py).  Round 2 shipped the general-prime
+    inverse and fused kernels with 28-104 bytes of scratch per lane."""
+    tool = os.path.join(ROOT, "tools", "kernel_resources.py")
+    src = os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip")
+    r = subprocess.run([sys.executable, tool, src, "15", "--require-no-scratch", "15"], capture_output=True, text=True, timeout=900)
+    rows = [l for l in r.stdout.splitlines() if "VGPRs" in l]
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert len(rows) == 48, len(rows)
