@@ -240,14 +240,15 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
         for (unsigned i = 0; i < n; i++) __builtin_amdgcn_s_sleep(32);
     }
 }
-// Cache policy of k_inverse15's stores (aux bits: 1 = sc0, 16 = sc1; 17 = write-through at system scope).  Written through,
-// the L2s hold no dirty lines when the kernel ends: the idle gap to the next launch shrinks from 12.1 to 8.7 us (launch log
-// of the stamped build) and the kernel alone runs 2 % faster in tools/kbench (0.1743-0.1756 -> 0.1694-0.1718 ms per 1024
-// transforms) -- but forward -> inverse pairs do not move (0.3254-0.3294 vs 0.3220-0.3294 ms) and whatever reads the result next
-// finds it in the memory-side cache instead of the L2, so the default policy stays
-// (profiles/r02_walk_order_and_store_policy.txt, L).
+// Cache policy of k_inverse15's (and k_polymul15's) coalesced 8-byte result stores (aux bits: 1 = sc0, 16 = sc1; 17 = written
+// through at system scope).  Written through, the L2s hold no dirty lines when the kernel ends: the write-back at the end of
+// the kernel -- part of the idle gap to the next launch -- disappears (round 2, launch log: 12.1 -> 8.7 us).  Measured again on
+// the frozen round-3 kernels (profiles/r03_structural_experiments.txt, batch C, three processes): inverse launches back to back
+// 0.1733 -> 0.1665 ms per 1024 transforms (-3.9 %), forward -> inverse pairs 0.3198 -> 0.3186 ms (-0.4 %, inside the noise but
+// never worse); sc1 alone gives the same, sc0 alone nothing.  Round 2 left it as a switch because the pairs did not move; it
+// ships since round 3 because a caller that runs inverse transforms on their own (decryption) gets the 4 %.
 #ifndef MI355NTT_INV15_AUX_ST
-#define MI355NTT_INV15_AUX_ST MI355NTT_STREAM_AUX_ST
+#define MI355NTT_INV15_AUX_ST 17
 #endif
 // Order in which k_inverse15's persistent workgroups walk the batch: 1 = from the last polynomial down.  A forward
 // transform is normally followed by an inverse over the same polynomials (and the other way round): walking them in
@@ -488,7 +489,7 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
         gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
-        store_coalesced<LOGN>(v, poly, fresh_t());
+        store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
         if (y + gridDim.x < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(y + gridDim.x) * G::N, fresh_t());
     }
 }
