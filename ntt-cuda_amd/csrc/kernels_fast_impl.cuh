@@ -419,7 +419,7 @@ struct SharedB {
 __host__ __device__ inline unsigned plain_division(unsigned division) { return (division & kSharedB) ? (division & kDivisionMask) : division; }
 
 }  // namespace mi355ntt
-#include "kernels_lat15.cuh"      // the small-batch kernels of n = 2^15 (need SharedB)
+#include "kernels_lat.cuh"      // the small-batch kernels (need SharedB)
 namespace mi355ntt {
 
 template <int HL, bool NEAR>
@@ -494,12 +494,32 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     }
 }
 
-// Small batches of n = 2^15 run the latency kernels (kernels_lat15.cuh: 64 waves per polynomial, two launches, twice the HBM
-// traffic), large ones the persistent single-pass kernels (one 1024-thread workgroup per CU walking the batch).  Measured
-// crossover on MI355X (profiles/r03_latency_cpp.txt): fwd+inv pairs 160 polynomials, fused products 176.  A persistent launch
-// costs whole iterations (ceil(num / CUs) polynomials per workgroup), so just above one polynomial per CU the latency kernels
-// win once more (320 polynomials: 142 us against 162 us per pair) until the second iteration is well filled.
+// Small batches run the latency kernels (kernels_lat.cuh: n/512 waves per polynomial, two launches, twice the HBM traffic),
+// large ones the single-pass kernels (one workgroup of n/32 threads per polynomial, persistent).  Switching points measured
+// on MI355X (profiles/r03_latency_cpp.txt): n = 2^15: fwd+inv pairs 160 polynomials, fused products 176 -- and once more just
+// above one polynomial per CU (257 .. 352 / 384), where a persistent launch of 1024-thread workgroups would pay a second,
+// mostly empty iteration (320 polynomials: 142 us against 162 us per pair).  Smaller n: see lat_threshold.
 // MI355NTT_LATENCY_PATH_MAX in the environment replaces the rule by a plain threshold (tuning / tests: 0 = never).
+// polynomials up to which the latency kernels win (fwd+inv pairs / fused products; tools/crossover_sizes.sh,
+// profiles/r03_latency_cpp.txt): the smaller the ring, the more polynomials it takes to fill the chip with n/512 waves each
+#define MI355NTT_LAT_T14 112u
+#define MI355NTT_LAT_T14M 176u
+#define MI355NTT_LAT_T13 128u
+#define MI355NTT_LAT_T13M 144u
+#define MI355NTT_LAT_T12 200u
+#define MI355NTT_LAT_T12M 256u
+#define MI355NTT_LAT_T11 256u
+#define MI355NTT_LAT_T11M 448u
+template <int LOGN>
+constexpr unsigned lat_threshold(bool fused)
+{
+    if (LOGN == 15) return fused ? 176u : 160u;
+    if (LOGN == 14) return fused ? MI355NTT_LAT_T14M : MI355NTT_LAT_T14;
+    if (LOGN == 13) return fused ? MI355NTT_LAT_T13M : MI355NTT_LAT_T13;
+    if (LOGN == 12) return fused ? MI355NTT_LAT_T12M : MI355NTT_LAT_T12;
+    return fused ? MI355NTT_LAT_T11M : MI355NTT_LAT_T11;
+}
+template <int LOGN>
 inline bool use_latency_path(unsigned num, bool fused)
 {
     static const long forced = [] {
@@ -507,8 +527,26 @@ inline bool use_latency_path(unsigned num, bool fused)
         return e ? (long)std::strtoul(e, nullptr, 10) : -1L;
     }();
     if (forced >= 0) return num <= (unsigned long)forced;
-    if (num <= (fused ? 176u : 160u)) return true;
-    return num > 256u && num <= (fused ? 384u : 352u);
+    if (num <= lat_threshold<LOGN>(fused)) return true;
+    return LOGN == 15 && num > 256u && num <= (fused ? 384u : 352u);
+}
+
+// the context's kernel class (FastTables::hl: bits 0-3 headroom class, bit 4 every prime near 2^k) as compile-time arguments
+template <class F>
+inline void dispatch_class(int hl, F&& f)
+{
+    const bool near = (hl & 16) != 0;
+    const int h = hl & 15;
+    using std::integral_constant;
+    if (near) {
+        if (h >= 6) f(integral_constant<int, 6>{}, integral_constant<bool, true>{});
+        else if (h >= 4) f(integral_constant<int, 4>{}, integral_constant<bool, true>{});
+        else f(integral_constant<int, 2>{}, integral_constant<bool, true>{});
+    } else {
+        if (h >= 6) f(integral_constant<int, 6>{}, integral_constant<bool, false>{});
+        else if (h >= 4) f(integral_constant<int, 4>{}, integral_constant<bool, false>{});
+        else f(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    }
 }
 
 // ---- fused: a = INTT( NTT(a) (.) bhat ) ---------------------------------------------------------
@@ -567,55 +605,24 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
 #ifdef MI355NTT_ONLY_HL4N      // tools/kbench.hip: one instantiation only (compile time)
-    if constexpr (LOGN == 15) {
-        k_forward15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    if constexpr (LOGN == 15) k_forward15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+#else
+    using L = LatGeo<LOGN>;
+    if (use_latency_path<LOGN>(num, false)) {
+        dispatch_class(hl, [&](auto hc, auto nc) {
+            constexpr int H = decltype(hc)::value;
+            constexpr bool NR = decltype(nc)::value;
+            k_lat_fwd_a<LOGN, H, NR><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, tw, pr, division, base);
+            k_lat_fwd_b<LOGN, H, NR><<<dim3(num << L::CH), dim3(64), 0, s>>>(d_a, tw, pr, division, base);
+        });
         return hipGetLastError();
     }
-#else
-    if constexpr (LOGN == 15) {
-        const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
-        const int h = hl & 15;
-        if (use_latency_path(num, false)) {
-#define MI355NTT_LAT8(K1, G1, B1, K2, G2, B2, H, N)                                         \
-            do {                                                                            \
-                K1<H, N><<<dim3(num * G1), dim3(B1), 0, s>>>(d_a, tw, pr, division, base);  \
-                K2<H, N><<<dim3(num * G2), dim3(B2), 0, s>>>(d_a, tw, pr, division, base);  \
-            } while (0)
-#define MI355NTT_LAT8_FWD(H, N) MI355NTT_LAT8(k_lat15_fwd_a, 8u, 512, k_lat15_fwd_b, 64u, 64, H, N)
-#define MI355NTT_LAT8_INV(H, N) MI355NTT_LAT8(k_lat15_inv_b, 64u, 64, k_lat15_inv_a, 8u, 512, H, N)
-            if (near) {
-                if (h >= 6) MI355NTT_LAT8_FWD(6, true);
-                else if (h >= 4) MI355NTT_LAT8_FWD(4, true);
-                else MI355NTT_LAT8_FWD(2, true);
-            } else {
-                if (h >= 6) MI355NTT_LAT8_FWD(6, false);
-                else if (h >= 4) MI355NTT_LAT8_FWD(4, false);
-                else MI355NTT_LAT8_FWD(2, false);
-            }
-            return hipGetLastError();
-        }
-        if (near) {
-            if (h >= 6) k_forward15<6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (h >= 4) k_forward15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_forward15<2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        } else {
-            if (h >= 6) k_forward15<6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (h >= 4) k_forward15<4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_forward15<2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        }
-    } else {
-        const bool near = (hl & 16) != 0;
-        hl &= 15;
-        if (near) {
-            if (hl >= 6) k_forward<LOGN, 6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (hl >= 4) k_forward<LOGN, 4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_forward<LOGN, 2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        } else {
-            if (hl >= 6) k_forward<LOGN, 6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (hl >= 4) k_forward<LOGN, 4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_forward<LOGN, 2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        }
-    }
+    dispatch_class(hl, [&](auto hc, auto nc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr bool NR = decltype(nc)::value;
+        if constexpr (LOGN == 15) k_forward15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_forward<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    });
 #endif
     return hipGetLastError();
 }
@@ -626,48 +633,24 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
 #ifdef MI355NTT_ONLY_HL4N
-    if constexpr (LOGN == 15) {
-        k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    if constexpr (LOGN == 15) k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+#else
+    using L = LatGeo<LOGN>;
+    if (use_latency_path<LOGN>(num, false)) {
+        dispatch_class(hl, [&](auto hc, auto nc) {
+            constexpr int H = decltype(hc)::value;
+            constexpr bool NR = decltype(nc)::value;
+            k_lat_inv_b<LOGN, H, NR><<<dim3(num << L::CH), dim3(64), 0, s>>>(d_a, tw, pr, division, base);
+            k_lat_inv_a<LOGN, H, NR><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, tw, pr, division, base);
+        });
         return hipGetLastError();
     }
-#else
-    if constexpr (LOGN == 15) {
-        const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
-        const int h = hl & 15;
-        if (use_latency_path(num, false)) {
-            if (near) {
-                if (h >= 6) MI355NTT_LAT8_INV(6, true);
-                else if (h >= 4) MI355NTT_LAT8_INV(4, true);
-                else MI355NTT_LAT8_INV(2, true);
-            } else {
-                if (h >= 6) MI355NTT_LAT8_INV(6, false);
-                else if (h >= 4) MI355NTT_LAT8_INV(4, false);
-                else MI355NTT_LAT8_INV(2, false);
-            }
-            return hipGetLastError();
-        }
-        if (near) {
-            if (h >= 6) k_inverse15<6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (h >= 4) k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_inverse15<2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        } else {
-            if (h >= 6) k_inverse15<6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (h >= 4) k_inverse15<4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_inverse15<2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        }
-    } else {
-        const bool near = (hl & 16) != 0;
-        hl &= 15;
-        if (near) {
-            if (hl >= 6) k_inverse<LOGN, 6, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (hl >= 4) k_inverse<LOGN, 4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_inverse<LOGN, 2, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        } else {
-            if (hl >= 6) k_inverse<LOGN, 6, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else if (hl >= 4) k_inverse<LOGN, 4, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-            else k_inverse<LOGN, 2, false><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        }
-    }
+    dispatch_class(hl, [&](auto hc, auto nc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr bool NR = decltype(nc)::value;
+        if constexpr (LOGN == 15) k_inverse15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_inverse<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    });
 #endif
     return hipGetLastError();
 }
@@ -676,52 +659,28 @@ template <int LOGN>
 hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr, unsigned num,
                       unsigned division, hipStream_t s)
 {
-    if constexpr (LOGN == 15) {
-        dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
-        const bool near = (hl & 16) != 0;      // every prime of the context is 2^k - small (FastTables::hl bit 4)
-        const int h = hl & 15;
-        if (use_latency_path(num, true)) {
-#define MI355NTT_LAT8_MUL(H, N)                                                              \
-            do {                                                                             \
-                k_lat15_fwd_a<H, N><<<dim3(num * 8u), dim3(512), 0, s>>>(d_a, twf, pr, plain_division(division), 0u);   \
-                k_lat15_mul_b<H, N><<<dim3(num * 64u), dim3(64), 0, s>>>(d_a, d_b, twf, twi, pr, division);            \
-                k_lat15_inv_a<H, N><<<dim3(num * 8u), dim3(512), 0, s>>>(d_a, twi, pr, plain_division(division), 0u);   \
-            } while (0)
-            if (near) {
-                if (h >= 6) MI355NTT_LAT8_MUL(6, true);
-                else if (h >= 4) MI355NTT_LAT8_MUL(4, true);
-                else MI355NTT_LAT8_MUL(2, true);
-            } else {
-                if (h >= 6) MI355NTT_LAT8_MUL(6, false);
-                else if (h >= 4) MI355NTT_LAT8_MUL(4, false);
-                else MI355NTT_LAT8_MUL(2, false);
-            }
-#undef MI355NTT_LAT8_MUL
-            return hipGetLastError();
-        }
-        if (near) {
-            if (h >= 6) k_polymul15<6, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-            else if (h >= 4) k_polymul15<4, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-            else k_polymul15<2, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-        } else {
-            if (h >= 6) k_polymul15<6, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-            else if (h >= 4) k_polymul15<4, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-            else k_polymul15<2, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
-        }
-    } else {
-        const bool near = (hl & 16) != 0;
-        hl &= 15;
-        dim3 g(num), b(Geo<LOGN>::T);
-        if (near) {
-            if (hl >= 6) k_polymul<LOGN, 6, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-            else if (hl >= 4) k_polymul<LOGN, 4, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-            else k_polymul<LOGN, 2, true><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-        } else {
-            if (hl >= 6) k_polymul<LOGN, 6, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-            else if (hl >= 4) k_polymul<LOGN, 4, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-            else k_polymul<LOGN, 2, false><<<g, b, 0, s>>>(d_a, d_b, twf, twi, pr, division);
-        }
+#ifndef MI355NTT_ONLY_HL4N
+    using L = LatGeo<LOGN>;
+    if (use_latency_path<LOGN>(num, true)) {
+        dispatch_class(hl, [&](auto hc, auto nc) {
+            constexpr int H = decltype(hc)::value;
+            constexpr bool NR = decltype(nc)::value;
+            k_lat_fwd_a<LOGN, H, NR><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, twf, pr, plain_division(division), 0u);
+            k_lat_mul_b<LOGN, H, NR><<<dim3(num << L::CH), dim3(64), 0, s>>>(d_a, d_b, twf, twi, pr, division);
+            k_lat_inv_a<LOGN, H, NR><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, twi, pr, plain_division(division), 0u);
+        });
+        return hipGetLastError();
     }
+    dispatch_class(hl, [&](auto hc, auto nc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr bool NR = decltype(nc)::value;
+        if constexpr (LOGN == 15) {
+            k_polymul15<H, NR><<<dim3(persistent_grid<LOGN>(num)), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        } else {
+            k_polymul<LOGN, H, NR><<<dim3(num), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division);
+        }
+    });
+#endif
     return hipGetLastError();
 }
 

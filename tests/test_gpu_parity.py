@@ -336,7 +336,7 @@ KERNEL_FORMS = {
 @pytest.mark.parametrize("num", [7, 200, 300])
 def test_every_kernel_form_at_n32768_matches_oracle(native, oracle, gpu, form, num):
     """n = 2^15 has six instantiations per kernel (headroom class x near-2^k or general prime: partial reduction, exact or
-    approximate quotient, fused butterfly) on two paths (the small-batch kernels of kernels_lat15.cuh for 7 and -- just above one
+    approximate quotient, fused butterfly) on two paths (the small-batch kernels of kernels_lat.cuh for 7 and -- just above one
     polynomial per CU -- 300 polynomials, the persistent single-pass kernels for 200; use_latency_path, kernels_fast_impl.cuh):
     every one of them against the oracle, with adversarial coefficients (0, 1, q-1, q-2) mixed into the random ones."""
     import torch

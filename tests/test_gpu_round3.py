@@ -86,19 +86,19 @@ def test_bfv_batch_limits_are_checked_before_the_data_is_touched(native, gpu):
     ctx.close()
 
 
-@pytest.mark.parametrize("num", [1, 3, 160, 161, 257, 352, 353])
-def test_small_batch_kernels_equal_the_persistent_ones(native, gpu, num):
-    """n = 2^15: the 8-coefficient latency kernels (kernels_lat15.cuh) and the persistent single-pass kernels produce the same
-    words for forward, inverse and the fused product on either side of every switching point of use_latency_path; the path is
-    forced through MI355NTT_LATENCY_PATH_MAX in a child process (the rule is read once per process)."""
+def _paths_child(n, num, force):
+    """forward, inverse round trip and fused product of `num` polynomials at ring degree n in a child process whose path
+    selection is forced through MI355NTT_LATENCY_PATH_MAX (the rule is read once per process); returns the two digests"""
     code = r'''
 import sys, hashlib
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import torch, numpy as np
 import ntt_cuda_amd as ntt, params as P
-num = %d
-ctx = ntt.NTTContext(32768, P.Q60, P.PSI60)
-a = torch.empty((num, 32768), dtype=torch.int64, device="cuda:0"); b = torch.empty_like(a)
+n, num = %d, %d
+qs = P.Q60
+psis = [next(x for x in (pow(g, (q - 1) // (2 * n), q) for g in range(2, 500)) if pow(x, n, q) == q - 1) for q in qs]
+ctx = ntt.NTTContext(n, qs, psis)
+a = torch.empty((num, n), dtype=torch.int64, device="cuda:0"); b = torch.empty_like(a)
 ctx.synth_splitmix(a, num, 11); ctx.synth_splitmix(b, num, 1000003)
 a0 = a.clone()
 ctx.forward_batch(a, num); ctx.forward_batch(b, num)
@@ -108,17 +108,37 @@ assert torch.equal(a, a0)
 ctx.polymul_batch(a, b, num)
 h.append(hashlib.sha256(ntt.to_host(a).tobytes()).hexdigest())
 print(" ".join(h))
-''' % (os.path.join(ROOT, "ntt-cuda_amd"), os.path.join(ROOT, "tests"), num)
-    outs = []
-    for force in ("100000", "0", None):
-        env = dict(os.environ)
-        env.pop("MI355NTT_LATENCY_PATH_MAX", None)
-        if force is not None:
-            env["MI355NTT_LATENCY_PATH_MAX"] = force
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout.strip().splitlines()[-1])
+''' % (os.path.join(ROOT, "ntt-cuda_amd"), os.path.join(ROOT, "tests"), n, num)
+    env = dict(os.environ)
+    env.pop("MI355NTT_LATENCY_PATH_MAX", None)
+    if force is not None:
+        env["MI355NTT_LATENCY_PATH_MAX"] = force
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout.strip().splitlines()[-1]
+
+
+@pytest.mark.parametrize("num", [1, 3, 160, 161, 257, 352, 353])
+def test_small_batch_kernels_equal_the_persistent_ones(native, gpu, num):
+    """n = 2^15: the 8-coefficient latency kernels (kernels_lat.cuh) and the persistent single-pass kernels produce the same
+    words for forward, inverse and the fused product on either side of every switching point of use_latency_path."""
+    outs = [_paths_child(32768, num, force) for force in ("100000", "0", None)]
     assert outs[0] == outs[1] == outs[2], outs
+
+
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("num", [1, 5, 300])
+def test_small_batch_kernels_at_every_ring_degree(native, oracle, gpu, n, num):
+    """n = 2^11 .. 2^14: the latency kernels (2, 3, 4, 5 stages in the "a" kernel: the partial rounds and the wave / register
+    exchange) against the single-pass kernels AND against the oracle's forward transform of the same recipe inputs."""
+    import hashlib
+    outs = [_paths_child(n, num, force) for force in ("100000", "0")]
+    assert outs[0] == outs[1], outs
+    qs = P.Q60
+    psis = [next(x for x in (pow(g, (q - 1) // (2 * n), q) for g in range(2, 500)) if pow(x, n, q) == q - 1) for q in qs]
+    prm = oracle.Params(n, qs, psis)
+    want = oracle.forward_batch(oracle.synth_batch(n, num, qs, 11), prm)
+    assert hashlib.sha256(np.ascontiguousarray(want).tobytes()).hexdigest() == outs[0].split()[0]
 
 
 def test_bench_two_ranks_on_one_gpu_dry_run(native, gpu):

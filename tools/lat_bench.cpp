@@ -4,7 +4,7 @@
 //
 //   hipcc -std=c++17 -O2 -x hip --offload-arch=gfx950 tools/lat_bench.cpp -x none -L ntt-cuda_amd -lmi355ntt \
 //         -Wl,-rpath,$PWD/ntt-cuda_amd -o ntt-cuda_amd/build/lat_bench        (the package Makefile does this: `make lat_bench`)
-//   ./lat_bench [calls=200] [rounds=7]      -> one JSON object on stdout (bench.py runs it and embeds the object)
+//   ./lat_bench [calls=200] [rounds=7] [n=32768]      -> one JSON object on stdout (bench.py runs it and embeds the object)
 //
 // "stream" figures: `calls` back-to-back calls on one stream between two events (launches pipeline; per-call time is the
 // steady-state cost of one call).  "graph" figures: the same calls captured once into a hipGraph (stream capture of the C ABI
@@ -94,10 +94,12 @@ int main(int argc, char** argv)
     Timer T;
     T.calls = argc > 1 ? atoi(argv[1]) : 200;
     T.rounds = argc > 2 ? atoi(argv[2]) : 7;
-    const unsigned n = 32768;
+    const unsigned n = argc > 3 ? (unsigned)atoi(argv[3]) : 32768;      // ring degree (2048 .. 32768); the BFV part runs at any of them
     // BASELINE configs[1]: one 60-bit prime; configs[4]: 4 x 60-bit + the special prime
     const u64 q5[5] = {1152921504606584833ULL, 1152921504598720513ULL, 1152921504597016577ULL, 1152921504595968001ULL, 1152921504595640321ULL};
-    const u64 psi5[5] = {4443670208963ULL, 100545759574150ULL, 31693996050849ULL, 88651361085495ULL, 9679305630873ULL};
+    u64 psi5[5] = {4443670208963ULL, 100545759574150ULL, 31693996050849ULL, 88651361085495ULL, 9679305630873ULL};
+    if (n != 32768)             // a primitive 2n-th root for the smaller ring: psi_32768^(32768 / n)
+        for (int i = 0; i < 5; i++) psi5[i] = mi355ntt_modpow(psi5[i], 32768 / n, q5[i]);
     CK(hipSetDevice(0));
     CK(hipStreamCreate(&T.s));
     CK(hipEventCreate(&T.e0)); CK(hipEventCreate(&T.e1));

@@ -24,7 +24,7 @@ for _ in range(reps):
 ctx.forward_batch(b, batch)
 for _ in range(max(6, reps // 4)):
     ctx.polymul_batch(a, b, batch)
-# the latency path (one polynomial: k_lat15_fwd_a + k_lat15_fwd_b, k_lat15_inv_b + k_lat15_inv_a, and the three-launch product)
+# the latency path (one polynomial: k_lat_fwd_a + k_lat_fwd_b, k_lat_inv_b + k_lat_inv_a, and the three-launch product)
 one, two = a[:32768].clone(), b[:32768].clone()
 for _ in range(max(6, reps // 4)):
     ctx.forward_batch(one, 1, 1)

@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         short = name.replace("(anonymous namespace)::", "").split("(")[0][-60:]
         acc[short][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
 for k in sorted(acc):
-    if any(x in k for x in ("k_forward", "k_inverse", "k_polymul", "k_pointwise", "k_lat15", "k_ntt30", "tables_check")):
+    if any(x in k for x in ("k_forward", "k_inverse", "k_polymul", "k_pointwise", "k_lat_", "k_ntt30", "tables_check")):
         print(k)
         for c in sorted(acc[k]):
             v = acc[k][c]
