@@ -24,7 +24,7 @@
 // ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
 // CXXFLAGS then stops the compilation instead of shipping a different kernel.
 #ifndef MI355NTT_LAB
-#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || \
+#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || \
     defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
     defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
     defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \
@@ -609,6 +609,12 @@ __device__ __forceinline__ unsigned fresh_lane_id()
 
 __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, BufRsrc dst, unsigned wave_byte_off, unsigned)
 {
+#ifdef MI355NTT_ABLATE_ROWS          // timing experiments only: no row stores (results are wrong)
+    u64 acc = 0;
+    static_for<32>([&](auto rc) { acc ^= v[decltype(rc)::value]; });
+    if (acc == 0x123456789ULL) slice[0] = acc;
+    return;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
@@ -692,6 +698,10 @@ __device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, 
 
 __device__ __forceinline__ void wave_load_rows(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
 {
+#ifdef MI355NTT_ABLATE_ROWS          // timing experiments only: no row loads (results are wrong)
+    static_for<32>([&](auto rc) { v[decltype(rc)::value] = (u64)fresh_lane_id() * 0x9E3779B97F4A7C15ULL + decltype(rc)::value; });
+    return;
+#endif
     if constexpr (MI355NTT_INV_MERGED_LOADS) {
         wave_load_rows_merged(v, slice, src, wave_byte_off, lane);
         return;
@@ -790,6 +800,9 @@ __device__ __forceinline__ void prio_hook(unsigned)
 template <int LOGN, int HL, int B, int JHI, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0>
 __device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
 {
+#ifdef MI355NTT_ABLATE_COMPUTE       // timing experiments only (tools/kbench.hip): no butterflies at all -- results are wrong
+    return;
+#endif
     constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
     constexpr bool EX = Lazy<HL>::EXACT;
     constexpr bool VEC = (B != Geo<LOGN>::B0);              // twiddles arrive in VGPRs: software-pipelined DEPTH - 1 groups ahead
@@ -844,6 +857,9 @@ template <int LOGN, int HL, int B, int JLO, bool NEAR = false, int PSPLIT = -2, 
 __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p,
                                          const TwPair* __restrict__ twn)      // twn: &primes[idx].twn[0] -- read where it is used (last round only)
 {
+#ifdef MI355NTT_ABLATE_COMPUTE
+    return;
+#endif
     constexpr InvPolicy<LOGN, HL> POL{};
     static_assert(!IN2Q || (!Lazy<HL>::EXACT && B == 0 && JLO == 0), "lazy inputs: first round of a class with 4q of headroom only");
     constexpr bool EX = Lazy<HL>::EXACT;
