@@ -53,6 +53,8 @@ hipError_t bfv_sample_encrypt(const BfvParams& p, const BfvDevice& d, const unsi
 
 // poly_add_negate_xq (bfv_keygen.cuh:80-93) on [R][n]
 hipError_t bfv_add_negate(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* e, hipStream_t s);
+// pk0 (holding NTT(e)) <- -(a_hat (.) s_hat + pk0): the key generation's product, sum and negation in the NTT domain
+hipError_t bfv_keygen_pk0(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* a_hat, const u64* s_hat, hipStream_t s);
 // poly_add_xq + divide_and_round_q_last_inplace_add_x2 + divide_and_round_q_last_inplace_loop_xq + weird_m_stuff
 // (bfv_encryption.cuh:110-208) on c [2][R][n], e [2][R][n], m [n]: one pass, same words as the four launches
 hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s, unsigned count = 1);

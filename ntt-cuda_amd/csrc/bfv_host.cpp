@@ -182,6 +182,15 @@ int mi355ntt_bfv_keygen(const mi355ntt_bfv* b, mi355ntt_u64* d_secret_key, mi355
     const size_t half = (size_t)R * b->p.n;
     BFV_ON_DEVICE(b);
     BFV_RC(mi355ntt_forward_batch(b->ntt, d_secret_key, R, R, stream));                                    /* :129 */
+    if (!mi355ntt_ctx_uses_literal_kernels(b->ntt)) {
+        /* exact arithmetic (every modulus Barrett-exact, or the caller asked for exact results): NTT(-(INTT(a s) + e)) =
+         * -(a s + NTT(e)), word for word -- one forward transform of e instead of an inverse and a forward of the product */
+        BFV_HIP(hipMemcpyAsync(d_public_key, d_e, half * sizeof(mi355ntt_u64), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        BFV_RC(mi355ntt_forward_batch(b->ntt, d_public_key, R, R, stream));
+        BFV_HIP(bfv_keygen_pk0(b->p, b->d, d_public_key, d_public_key + half, d_secret_key, (hipStream_t)stream));
+        return MI355NTT_OK;
+    }
+    /* literal contexts follow the reference's own sequence (its words, including where its Barrett is inexact) */
     BFV_RC(mi355ntt_pointwise_mul(b->ntt, d_public_key, d_public_key + half, d_secret_key, R, R, stream)); /* :131-132 */
     BFV_RC(mi355ntt_inverse_batch(b->ntt, d_public_key, R, R, stream));                                    /* :133 */
     BFV_HIP(bfv_add_negate(b->p, b->d, d_public_key, d_e, (hipStream_t)stream));                           /* :144 */

@@ -27,6 +27,23 @@ k_add_negate(u64* __restrict__ a, const u64* __restrict__ b, unsigned n, const B
     a[i] = ra * (ra != q);
 }
 
+// keygen in the NTT domain: pk0 <- -(a_hat (.) s_hat + pk0) with pk0 holding NTT(e) on entry.  The reference forms
+// NTT(-(INTT(a_hat (.) s_hat) + e)) (bfv_keygen.cuh:131-145: barrett_batch_3param, inverseNTT_batch, poly_add_negate_xq,
+// forwardNTT_batch); the transform is linear and every step exact, so the canonical words are the same -- without the inverse
+// transform.
+__global__ void __launch_bounds__(kBlock)
+k_keygen_pk0(u64* __restrict__ pk0, const u64* __restrict__ a_hat, const u64* __restrict__ s_hat, unsigned n,
+             const BfvPrime* __restrict__ primes)
+{
+    const unsigned y = blockIdx.y;
+    const BfvPrime p = primes[y];
+    const size_t i = (size_t)y * n + blockIdx.x * kBlock + threadIdx.x;
+    u64 ra = barrett_mul(a_hat[i], s_hat[i], p.q, p.mu, p.k) + pk0[i];
+    if (ra >= p.q) ra -= p.q;
+    ra = p.q - ra;
+    pk0[i] = ra * (ra != p.q);
+}
+
 // one column i of one half h of the ciphertext: poly_add_xq on all R polynomials (note `>`, bfv_encryption.cuh:180),
 // +half on the last one (:110-124), subtract-and-scale on the others (:126-171), message term on c0 (:186-208)
 __global__ void __launch_bounds__(kBlock)
@@ -230,6 +247,12 @@ hipError_t bfv_sample_encrypt(const BfvParams& p, const BfvDevice& d, const unsi
 hipError_t bfv_add_negate(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* e, hipStream_t s)
 {
     k_add_negate<<<dim3(p.n / kBlock, p.R), kBlock, 0, s>>>(pk0, e, p.n, d.d_prime);
+    return hipGetLastError();
+}
+
+hipError_t bfv_keygen_pk0(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* a_hat, const u64* s_hat, hipStream_t s)
+{
+    k_keygen_pk0<<<dim3(p.n / kBlock, p.R), kBlock, 0, s>>>(pk0, a_hat, s_hat, p.n, d.d_prime);
     return hipGetLastError();
 }
 
