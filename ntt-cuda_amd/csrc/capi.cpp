@@ -70,6 +70,8 @@ static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, uns
 {
     if (c->literal) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
     if (c->split16) {
+        // large batches: the coupling stage rides in the loads of the lower halves' launch (1.5 passes over memory instead of 2)
+        if (fast_forward_split16_ok(c->fast, num)) return fast_forward_split16(c->fast, d_a, num, division, base, s);
         hipError_t e = compat_ct_stage(d_a, c->n, c->d_psi + (size_t)base * c->n, 1, num, division, mods_from(c, base, division), s);
         if (e != hipSuccess) return e;
         return fast_forward_batch(c->fast, d_a, 2 * num, 2 * division, 2 * base, s);
@@ -221,10 +223,12 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
         const unsigned h_n = n / 2;
         std::vector<u64> vp((size_t)2 * num_primes * h_n), vi((size_t)2 * num_primes * h_n);
         PrimeParams vprime[kMaxPrimes];
+        u64 split_fwd[kMaxPrimes];
         for (unsigned i = 0; i < num_primes; i++)
             for (unsigned h = 0; h < 2; h++) {
                 const unsigned v = 2 * i + h;
                 vprime[v] = c->prime[i];
+                split_fwd[v] = hp[(size_t)i * n + 1];                               // psi^bitrev(1): stage 1 of the full-size transform
                 vprime[v].ninv = modinv(h_n % c->prime[i].q, c->prime[i].q);       // the half-size transform scales by (n/2)^-1 ...
                 u64* tp = vp.data() + (size_t)v * h_n;                              // ... and the last GS stage halves once more
                 u64* ti = vi.data() + (size_t)v * h_n;
@@ -235,7 +239,7 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
                         ti[L + p] = hi[(size_t)i * n + 2 * L + h * L + p];
                     }
             }
-        e = fast_tables_create(&c->fast, h_n, 2 * num_primes, vprime, vp.data(), vi.data(), nullptr, nullptr);
+        e = fast_tables_create(&c->fast, h_n, 2 * num_primes, vprime, vp.data(), vi.data(), nullptr, nullptr, split_fwd);
         c->split16 = (e == hipSuccess);
     } else {
         e = fast_tables_create(&c->fast, n, num_primes, c->prime, hp.data(), hi.data(), c->d_psi, c->d_psiinv);

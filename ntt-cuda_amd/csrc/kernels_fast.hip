@@ -73,7 +73,7 @@ ModSet shifted(const ModSet& m, unsigned base, unsigned division)
 
 // ------------------------------------------------------------------------------------------------
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
-                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv)
+                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd)
 {
     t->n = n;
     t->log_n = 0;
@@ -97,11 +97,9 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         PrimeDev& d = pd[i];
         d.q = pp.q;
         d.nq = 0ULL - pp.q;
-        d.ninv = pp.ninv;
-        d.ninv_p = shoup(pp.ninv, pp.q);
-        const u64 w1 = h_psiinv[(size_t)i * n + 1];           // psi^-bitrev(1): the single twiddle of the last GS stage
-        d.w1n = mulmod(w1, pp.ninv, pp.q);
-        d.w1n_p = shoup(d.w1n, pp.q);
+        d.rsv0_ = d.rsv1_ = 0;
+        d.sf = split_fwd ? split_fwd[i] : 0;                   // (n = 2^16 contexts: the stage that couples the two halves)
+        d.sf_p = split_fwd ? shoup(split_fwd[i], pp.q) : 0;
         d.mu = pp.mu;
         d.k = pp.k;
         const unsigned g = pp.k - 1 < 16 ? pp.k - 1 : 16;
@@ -223,6 +221,15 @@ hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsig
         return compat_forward_batch(d_a, t.n, t.d_psi + (size_t)prime_base * t.n, num, division,
                                     shifted(t.mods, prime_base, division), s);
     }
+}
+
+// n = 2^16 as two half-size transforms per polynomial with the coupling stage fused into the lower half's loads (t holds the
+// 2 P "virtual primes" of n/2 = 2^15; num, division, prime_base count full-size polynomials / real primes)
+bool fast_forward_split16_ok(const FastTables& t, unsigned num) { return t.log_n == 15 && fast_fwd_split_ok_15(num); }
+hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
+{
+    return fast_fwd_split_16(t.hl, d_a, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const PrimeDev*>(t.d_primes), num,
+                             division, prime_base, s);
 }
 
 hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)

@@ -268,7 +268,24 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 // forward : load(layout 10) R1 | sync, exchange 10->5 | R2 | wave transpose 5->0 | R3 | canon | wave-local row store
 // inverse : wave-local row load (layout 0) | R1' | wave transpose 0->5 | R2' | sync, exchange 5->10 | R3' | canon | store
 // ================================================================================================
-template <int HL, bool NEAR>
+// the fused coupling stage of SPLIT = 1 works through the 32 registers in four chunks of eight: registers 4c .. 4c+3 and 16 + 4c ..
+__host__ __device__ constexpr int split_reg(int c, int i) { return 4 * c + (i >> 1) + ((i & 1) << 4); }
+template <int C>
+__device__ __forceinline__ void split_partner_loads(u64 (&V)[8], BufRsrc hrs, unsigned voff)
+{
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        V[i] = buf_load_u64(hrs, voff, ((unsigned)split_reg(C, i) << Geo<15>::B0) * 8u);
+    });
+}
+
+// SPLIT (n = 2^16 contexts: two half-size transforms per polynomial y, halves h = 0 / 1 at a + (2y + h) 2^15, tables and constants
+// of "virtual prime" 2 i + h): the workgroup transforms both halves of its polynomial one after the other.  Before the rounds of
+// the lower half it reads the partner coefficients V of the upper half, forms T = V w (the stage that couples the halves), stores
+// U - T (canonical: the upper half's input) in place over V and keeps U + T in registers as its own input (in [0, 2q): every
+// class's bound tracking admits that, see fwd_reduce_mask); the upper half is then an ordinary transform of what the same threads
+// stored.  Reads 1.5 x, writes 1.5 x the polynomial in ONE launch instead of 2 x / 2 x in two (a stage kernel in front).
+template <int HL, bool NEAR, int SPLIT = 0>
 __global__ void __launch_bounds__(1024, 4)
 k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
             unsigned prime_base, unsigned num)
@@ -288,7 +305,13 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     MI355NTT_WGSTAMP(0);
     stagger_start<MI355NTT_STAGGER_FWD, MI355NTT_STAGGER_FWD_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(y) * G::N, fresh_t());
+    // (SPLIT: half h of polynomial y is the half-size polynomial 2 y + h)
+    [[maybe_unused]] unsigned h = 0;
+    auto half_of = [](unsigned yy, unsigned hh) { return SPLIT ? 2 * yy + hh : yy; };
+    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(y, 0)) * G::N, fresh_t());
+    [[maybe_unused]] u64 PV[2][SPLIT ? 8 : 1];           // SPLIT: partner coefficients of the coupling stage, double-buffered
+    if constexpr (SPLIT != 0)
+        split_partner_loads<0>(PV[0], make_rsrc(a + (size_t)(half_of(y, 0) + 1) * G::N, G::N * 8u), fresh_t() * 8u);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
@@ -296,13 +319,33 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
     unsigned ymod = __builtin_amdgcn_readfirstlane(blockIdx.x % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
-    for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
+    while (y < num) {
         const unsigned ynext = y + gridDim.x;
-        const unsigned idx = prime_base + ymod;
+        const unsigned idx = SPLIT ? 2 * (prime_base + ymod) + h : prime_base + ymod;
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(y) * G::N;
+        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(half_of(y, h)) * G::N;
+        if constexpr (SPLIT != 0) if (h == 0) {
+            // the stage that couples the halves, eight partner coefficients at a time, software-pipelined: chunk c + 1 is in flight
+            // while chunk c is multiplied; chunk 0 was requested together with this polynomial's own loads (previous iteration)
+            const BufRsrc hrs = make_rsrc(poly + G::N, G::N * 8u);
+            const unsigned voff = fresh_t() * 8u;
+            const u64 cq = (u64)Lazy<HL>::TQ * p.q;
+            static_for<4>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c < 3) split_partner_loads<c + 1>(PV[(c + 1) & 1], hrs, voff);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, r = split_reg(c, i);
+                    const u64 U = v[r], Vi = PV[c & 1][i];
+                    const u64 Tm = Lazy<HL>::EXACT ? mul_shoup2(Vi, p.sf, p.sf_p, p.nq) : mul_shoup4m<true>(Vi, p.sf, p.sf_p, p.nq);
+                    buf_store_u64(hrs, voff, ((unsigned)r << G::B0) * 8u, canon_2q(reduce_2q_sel<NEAR>(U + cq - Tm, p), p.q));
+                    v[r] = reduce_2q_sel<NEAR>(U + Tm, p);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
         MI355NTT_STAMPV(0, 0);
 #if defined(MI355NTT_STAMPS) && MI355NTT_STAMPS == 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostic build only: separates the load wait from round 1
@@ -326,10 +369,31 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic instead of a VGPR kept live across the loop)
         wave_store_rows(v, lds + wave_s * WAVE_SLICE_WORDS, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
         MI355NTT_STAMPV(-1, 5);
-        if (ynext < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N, fresh_t());
+        if constexpr (SPLIT != 0) {
+            // (the partner buffers carry values only from here to the top of a lower-half iteration: on every other path they are
+            // re-defined as "anything", without an instruction, so that they are not kept alive across the rounds)
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("" : "=v"(PV[0][i]), "=v"(PV[1][i]));
+            if (h == 0) {
+                // next: the upper half of the same polynomial -- what this thread stored in the coupling stage above
+                load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly + G::N, fresh_t());
+            } else if (ynext < num) {
+                load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(ynext, 0)) * G::N, fresh_t());
+                split_partner_loads<0>(PV[0], make_rsrc(a + (size_t)(half_of(ynext, 0) + 1) * G::N, G::N * 8u), fresh_t() * 8u);
+            }
+        } else {
+            if (ynext < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N, fresh_t());
+        }
         MI355NTT_STAMPV(6, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
+        if (SPLIT != 0 && h == 0) {
+            h = 1;                       // same polynomial, upper half
+        } else {
+            h = 0;
+            y = ynext;
+            ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep);
+        }
     }
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
@@ -698,6 +762,9 @@ MI355NTT_DECLARE_SIZE(12)
 MI355NTT_DECLARE_SIZE(13)
 MI355NTT_DECLARE_SIZE(14)
 MI355NTT_DECLARE_SIZE(15)
+bool fast_fwd_split_ok_15(unsigned num);                  // (kernels_fast_n16.hip)
+hipError_t fast_fwd_split_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
+                             hipStream_t s);
 
 #define MI355NTT_DEFINE_SIZE(LOGN)                                                                                           \
     hipError_t fast_fwd_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,     \

@@ -1,0 +1,30 @@
+// n = 2^16 on the n = 2^15 kernels: the launches whose first stage couples the two half-size transforms of a polynomial
+// (k_forward15<.., SPLIT>, kernels_fast_impl.cuh); a translation unit of its own so the six extra instantiations compile in
+// parallel with the rest
+#include "kernels_fast_impl.cuh"
+
+namespace mi355ntt {
+
+// n = 2^16 forward on a 2^15 table set: one launch, each workgroup transforms both halves of its polynomials (coupling stage fused)
+static bool fwd_split_ok(unsigned num) { return !use_latency_path<15>(2 * num, false); }
+static hipError_t launch_fwd_split16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
+                                     hipStream_t s)
+{
+#ifndef MI355NTT_ONLY_HL4N
+    dim3 g(persistent_grid<15>(num)), b(1024);
+    dispatch_class(hl, [&](auto hc, auto nc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr bool NR = decltype(nc)::value;
+        k_forward15<H, NR, 1><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    });
+#endif
+    return hipGetLastError();
+}
+
+bool fast_fwd_split_ok_15(unsigned num) { return fwd_split_ok(num); }
+hipError_t fast_fwd_split_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
+                             hipStream_t s)
+{
+    return launch_fwd_split16(hl, d_a, tw, pr, num, division, base, s);
+}
+}  // namespace mi355ntt

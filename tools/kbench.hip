@@ -29,7 +29,7 @@ int main(int argc, char** argv)
     std::vector<TwPair> tw(n);
     for (unsigned i = 0; i < n; i++) tw[i] = TwPair{tab[i], shoup(tab[i], q)};   // layout irrelevant for timing
     PrimeDev d{};
-    d.q = q; d.nq = 0ULL - q; d.ninv = pp.ninv; d.ninv_p = shoup(pp.ninv, q); d.w1n = 12345; d.w1n_p = shoup(12345, q);
+    d.q = q; d.nq = 0ULL - q;
     d.mu = pp.mu; d.k = pp.k; d.red_sh1 = pp.k - 17; d.red_sh2 = 16; d.red_c = (u32)((((u128)1) << (31 + pp.k)) / q);
     for (int j = 0; j < 32; j++) d.twn[j] = TwPair{tab[j] % q, shoup(tab[j] % q, q)};   // (timing only)
     d.delta = (u32)((1ull << pp.k) - q); d.near_sh = pp.k - 32; d.near_mask = (u32)((1ull << (pp.k - 32)) - 1);
