@@ -623,7 +623,9 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
     const unsigned y = blockIdx.x;
-    const unsigned idx = __builtin_amdgcn_readfirstlane(y % division);      // (uniform: keeps the table and constant addresses in SGPRs)
+    unsigned idx = __builtin_amdgcn_readfirstlane(y % division);
+    asm volatile("" : "+s"(idx));        // pinned in an SGPR: the table and constant addresses derived from it stay scalar (the
+                                         // compiler otherwise forms them on the VALU and keeps a vector copy alive: a spill)
     const PrimeDev p = primes[idx];
     u64* poly = a + (size_t)y * G::N;
     const u64* bp = bhat + (size_t)sb.index(y, idx, division) * G::N;

@@ -237,7 +237,8 @@ k_lat_fwd_a(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     __shared__ u64 lds[L::NST2 ? 4096 : 1];
     const unsigned y = blockIdx.x >> L::GB, g = blockIdx.x & ((1u << L::GB) - 1u);
     const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));        // (pinned in an SGPR: the addresses derived from it stay scalar)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * L::N;
     const BufRsrc twr = make_rsrc(twp, L::N * 16u), prs = make_rsrc(a + (size_t)y * L::N, L::N * 8u);
@@ -263,7 +264,8 @@ k_lat_inv_a(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     __shared__ u64 lds[L::NST2 ? 4096 : 1];
     const unsigned y = blockIdx.x >> L::GB, g = blockIdx.x & ((1u << L::GB) - 1u);
     const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));        // (pinned in an SGPR: the addresses derived from it stay scalar)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * L::N;
     const BufRsrc twr = make_rsrc(twp, L::N * 16u), prs = make_rsrc(a + (size_t)y * L::N, L::N * 8u);
@@ -341,7 +343,8 @@ k_lat_fwd_b(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     if (guard_says_skip(primes, prime_base)) return;
     __shared__ u64 slice[LAT_SLICE_WORDS];
     const unsigned y = blockIdx.x >> (LOGN - 9), c = blockIdx.x & ((1u << (LOGN - 9)) - 1u), lane = threadIdx.x;
-    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));        // (pinned in an SGPR: the addresses derived from it stay scalar)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * (1u << LOGN);
     const BufRsrc twr = make_rsrc(twp, (1u << LOGN) * 16u), prs = make_rsrc(a + (size_t)y * (1u << LOGN), (1u << LOGN) * 8u);
@@ -359,7 +362,8 @@ k_lat_inv_b(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     if (guard_says_skip(primes, prime_base)) return;
     __shared__ u64 slice[LAT_SLICE_WORDS];
     const unsigned y = blockIdx.x >> (LOGN - 9), c = blockIdx.x & ((1u << (LOGN - 9)) - 1u), lane = threadIdx.x;
-    const unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);      // (uniform: addresses stay in SGPRs)
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));        // (pinned in an SGPR: the addresses derived from it stay scalar)
     const PrimeDev p = primes[idx];
     const TwPair* twp = tw + (size_t)idx * (1u << LOGN);
     const BufRsrc twr = make_rsrc(twp, (1u << LOGN) * 16u), prs = make_rsrc(a + (size_t)y * (1u << LOGN), (1u << LOGN) * 8u);
@@ -379,7 +383,8 @@ k_lat_mul_b(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     const SharedB sb(division);
     __shared__ u64 slice[LAT_SLICE_WORDS];
     const unsigned y = blockIdx.x >> (LOGN - 9), c = blockIdx.x & ((1u << (LOGN - 9)) - 1u), lane = threadIdx.x;
-    const unsigned idx = __builtin_amdgcn_readfirstlane(y % division);
+    unsigned idx = __builtin_amdgcn_readfirstlane(y % division);
+    asm volatile("" : "+s"(idx));
     const PrimeDev p = primes[idx];
     const TwPair* tf = twf + (size_t)idx * (1u << LOGN);
     const TwPair* ti = twi + (size_t)idx * (1u << LOGN);
