@@ -83,11 +83,15 @@ struct FastTables {
 
 // split_fwd (n = 2^16 contexts only, else null): per (virtual) prime the twiddle of the stage that couples the two halves
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
-                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd = nullptr);
+                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd = nullptr,
+                              const u64* split_inv = nullptr);
 // n = 2^16 forward as two launches over half-size transforms, the coupling stage fused into the first (1.5 instead of 2 passes
 // over memory); _ok: the batch is large enough for the persistent kernels
 bool fast_forward_split16_ok(const FastTables& t, unsigned num);
 hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);
+// (same condition; d_bhat: null, or a factor in the NTT domain -- one polynomial per polynomial of d_a -- multiplied in on the way in)
+hipError_t fast_inverse_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s,
+                                const u64* d_bhat = nullptr);
 void fast_tables_destroy(FastTables* t);
 // measurement helper: a stream-ordered clock probe (20 us) and the shader clock it measured (the read synchronises)
 hipError_t fast_clock_probe(const FastTables& t, hipStream_t s);

@@ -73,7 +73,7 @@ ModSet shifted(const ModSet& m, unsigned base, unsigned division)
 
 // ------------------------------------------------------------------------------------------------
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
-                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd)
+                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd, const u64* split_inv)
 {
     t->n = n;
     t->log_n = 0;
@@ -97,7 +97,8 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         PrimeDev& d = pd[i];
         d.q = pp.q;
         d.nq = 0ULL - pp.q;
-        d.rsv0_ = d.rsv1_ = 0;
+        d.si = split_inv ? mulmod(split_inv[i], (pp.q >> 1) + 1, pp.q) : 0;       // (... and its inverse counterpart, times 2^-1)
+        d.si_p = split_inv ? shoup(d.si, pp.q) : 0;
         d.sf = split_fwd ? split_fwd[i] : 0;                   // (n = 2^16 contexts: the stage that couples the two halves)
         d.sf_p = split_fwd ? shoup(split_fwd[i], pp.q) : 0;
         d.mu = pp.mu;
@@ -229,6 +230,13 @@ bool fast_forward_split16_ok(const FastTables& t, unsigned num) { return t.log_n
 hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
     return fast_fwd_split_16(t.hl, d_a, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const PrimeDev*>(t.d_primes), num,
+                             division, prime_base, s);
+}
+
+hipError_t fast_inverse_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s,
+                                const u64* d_bhat)
+{
+    return fast_inv_split_16(t.hl, d_a, d_bhat, reinterpret_cast<const TwPair*>(t.d_inv), reinterpret_cast<const PrimeDev*>(t.d_primes), num,
                              division, prime_base, s);
 }
 

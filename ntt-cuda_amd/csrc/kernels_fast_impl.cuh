@@ -268,14 +268,30 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 // forward : load(layout 10) R1 | sync, exchange 10->5 | R2 | wave transpose 5->0 | R3 | canon | wave-local row store
 // inverse : wave-local row load (layout 0) | R1' | wave transpose 0->5 | R2' | sync, exchange 5->10 | R3' | canon | store
 // ================================================================================================
-// the fused coupling stage of SPLIT = 1 works through the 32 registers in four chunks of eight: registers 4c .. 4c+3 and 16 + 4c ..
-__host__ __device__ constexpr int split_reg(int c, int i) { return 4 * c + (i >> 1) + ((i & 1) << 4); }
-template <int C>
-__device__ __forceinline__ void split_partner_loads(u64 (&V)[8], BufRsrc hrs, unsigned voff)
+// The fused coupling stage of SPLIT = 1 reads the partner half through the wave's private LDS slice: `buffer_load_dwordx4 ... lds`
+// (LDS-direct: the data never touches a VGPR; lane L's 16 bytes land at M0 + 16 L whatever its global offset -- probed on the
+// hardware, tools/probe/lds_direct.hip) moves two 512-byte partner rows per instruction, lanes 0..31 the row r and lanes 32..63 the
+// row r + 1 of this wave's 64 columns.  Four phases of eight rows, double-buffered in the slice's first 8 KiB: phase 0 is
+// requested at the tail of the previous iteration, phase c + 1 while phase c is multiplied.  (Through registers, eight partner
+// loads per thread at a time, the stage cost 24 us per polynomial -- four exposed HBM latencies: r03 first version.)
+typedef __attribute__((address_space(3))) void* LdsPtr;
+template <int PH>
+__device__ __forceinline__ void split_partner_fetch(BufRsrc hrs, u64* slice, unsigned wave_s, unsigned lane)
+{
+    const unsigned voff = ((lane & 32u) << 8) | ((lane & 31u) << 4);           // upper half-wave: the next row (8192 B further)
+    static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(hrs, (LdsPtr)(slice + (PH & 1) * 512 + j * 128), 16, voff,
+                                                 ((unsigned)((8 * PH + 2 * j) << Geo<15>::B0) + (wave_s << 6)) * 8u, 0, 0);
+    });
+}
+// (row 8 PH + i of this wave, this lane's column)
+template <int PH>
+__device__ __forceinline__ void split_partner_read(u64 (&V)[8], const u64* slice, unsigned lane)
 {
     static_for<8>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        V[i] = buf_load_u64(hrs, voff, ((unsigned)split_reg(C, i) << Geo<15>::B0) * 8u);
+        V[i] = slice[(PH & 1) * 512 + (i >> 1) * 128 + (i & 1) * 64 + lane];
     });
 }
 
@@ -309,9 +325,8 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     [[maybe_unused]] unsigned h = 0;
     auto half_of = [](unsigned yy, unsigned hh) { return SPLIT ? 2 * yy + hh : yy; };
     load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(y, 0)) * G::N, fresh_t());
-    [[maybe_unused]] u64 PV[2][SPLIT ? 8 : 1];           // SPLIT: partner coefficients of the coupling stage, double-buffered
     if constexpr (SPLIT != 0)
-        split_partner_loads<0>(PV[0], make_rsrc(a + (size_t)(half_of(y, 0) + 1) * G::N, G::N * 8u), fresh_t() * 8u);
+        split_partner_fetch<0>(make_rsrc(a + (size_t)(half_of(y, 0) + 1) * G::N, G::N * 8u), lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
@@ -327,18 +342,28 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
         u64* poly = a + (size_t)MI355NTT_POLY_SLOT(half_of(y, h)) * G::N;
         if constexpr (SPLIT != 0) if (h == 0) {
-            // the stage that couples the halves, eight partner coefficients at a time, software-pipelined: chunk c + 1 is in flight
-            // while chunk c is multiplied; chunk 0 was requested together with this polynomial's own loads (previous iteration)
+            // the stage that couples the halves, eight partner rows at a time (phase c + 1 in flight while phase c is multiplied;
+            // phase 0 was requested together with this polynomial's own loads, at the tail of the previous iteration)
             const BufRsrc hrs = make_rsrc(poly + G::N, G::N * 8u);
-            const unsigned voff = fresh_t() * 8u;
+            u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
             const u64 cq = (u64)Lazy<HL>::TQ * p.q;
             static_for<4>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                if constexpr (c < 3) split_partner_loads<c + 1>(PV[(c + 1) & 1], hrs, voff);
+                if constexpr (c < 3) split_partner_fetch<c + 1>(hrs, slice, wave_s, fresh_lane_id());     // (buffer (c + 1) & 1: read out in phase c - 1)
+                // hipcc does not order an LDS read behind the LDS-direct load that fills it: counted wait for phase c's four
+                // loads -- behind them in the queue are phase c - 1's eight stores and phase c + 1's four loads (loads, stores and
+                // LDS-direct loads retire in issue order on one counter)
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (c < 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                u64 PV[8];
+                split_partner_read<c>(PV, slice, fresh_lane_id());
+                wave_lds_fence();                         // the buffer is free for phase c + 2 before anything is requested into it
+                const unsigned voff = fresh_t() * 8u;
                 static_for<8>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, r = split_reg(c, i);
-                    const u64 U = v[r], Vi = PV[c & 1][i];
+                    constexpr int i = decltype(ic)::value, r = 8 * c + i;
+                    const u64 U = v[r], Vi = PV[i];
                     const u64 Tm = Lazy<HL>::EXACT ? mul_shoup2(Vi, p.sf, p.sf_p, p.nq) : mul_shoup4m<true>(Vi, p.sf, p.sf_p, p.nq);
                     buf_store_u64(hrs, voff, ((unsigned)r << G::B0) * 8u, canon_2q(reduce_2q_sel<NEAR>(U + cq - Tm, p), p.q));
                     v[r] = reduce_2q_sel<NEAR>(U + Tm, p);
@@ -370,16 +395,12 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         wave_store_rows(v, lds + wave_s * WAVE_SLICE_WORDS, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
         MI355NTT_STAMPV(-1, 5);
         if constexpr (SPLIT != 0) {
-            // (the partner buffers carry values only from here to the top of a lower-half iteration: on every other path they are
-            // re-defined as "anything", without an instruction, so that they are not kept alive across the rounds)
-#pragma unroll
-            for (int i = 0; i < 8; i++) asm volatile("" : "=v"(PV[0][i]), "=v"(PV[1][i]));
             if (h == 0) {
                 // next: the upper half of the same polynomial -- what this thread stored in the coupling stage above
                 load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly + G::N, fresh_t());
             } else if (ynext < num) {
                 load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(ynext, 0)) * G::N, fresh_t());
-                split_partner_loads<0>(PV[0], make_rsrc(a + (size_t)(half_of(ynext, 0) + 1) * G::N, G::N * 8u), fresh_t() * 8u);
+                split_partner_fetch<0>(make_rsrc(a + (size_t)(half_of(ynext, 0) + 1) * G::N, G::N * 8u), lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
             }
         } else {
             if (ynext < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N, fresh_t());
@@ -459,6 +480,154 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         MI355NTT_STAMP2(it, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;
+    }
+    MI355NTT_STAMP_FLUSH
+    MI355NTT_WGSTAMP(7);
+}
+
+// n = 2^16 contexts (two half-size transforms per polynomial, see k_forward15 SPLIT; a kernel of its own so that k_inverse15's
+// code stays what was tuned): the UPPER half of polynomial y first -- an ordinary half-size inverse transform, its
+// result Y stored in place -- then the lower half, whose result X stays in registers for the stage that couples the halves (the last
+// GS stage of the full-size transform: (X + Y) / 2 below, (X - Y) psi^-bitrev(1) / 2 above; the half-size transforms scale by
+// (n/2)^-1).  Y comes back through the wave's LDS slice by LDS-direct loads (split_partner_fetch): the first sixteen rows are
+// requested right behind the exchange and arrive during the last round, the other sixteen while the first are combined.
+// Reads 1.5 x, writes 1.5 x the polynomial in ONE launch instead of 2 x / 2 x in two (a stage kernel behind).
+template <int HL, bool NEAR, bool MUL = false>
+__global__ void __launch_bounds__(1024, 4)
+k_inverse15_split(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+            unsigned prime_base, unsigned num)
+{
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
+    constexpr int LOGN = 15, SPLIT = 1;
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    // thread-derived values are rebuilt where they are used (wave index in an SGPR, lane index from v_mbcnt), as in
+    // k_forward15: kept live across the polynomial loop they are spills in the general-prime instantiations
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+s"(wave_s));
+    auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
+    u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
+    u64 v[32];
+    unsigned y = blockIdx.x;
+    if (y >= num) return;
+    MI355NTT_WGSTAMP(0);
+    stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
+    MI355NTT_WGSTAMP(1);
+    // (SPLIT: half h of the polynomial at position pos is the half-size polynomial 2 pos + h)
+    [[maybe_unused]] unsigned h = SPLIT ? 1u : 0u;
+    auto half_at = [&](unsigned yy, unsigned hh) { return SPLIT ? 2 * MI355NTT_INV_POS(yy) + hh : MI355NTT_INV_POS(yy); };
+    // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic)
+    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(half_at(y, h)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+    [[maybe_unused]] int it = 0;
+    MI355NTT_STAMP_DECL
+    // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
+    // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
+    // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(MI355NTT_INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    if (MI355NTT_INV_DESCENDING && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
+    asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
+    while (y < num) {
+        const unsigned ynext = y + gridDim.x;
+        h = __builtin_amdgcn_readfirstlane(h);
+        asm volatile("" : "+s"(h));                      // (uniform, but carried around the loop it ends up in a VGPR -- and the prime's address with it)
+        const unsigned idx = SPLIT ? 2 * (prime_base + ymod) + h : prime_base + ymod;
+        const PrimeDev p = primes[idx];
+        const TwPair* twp = tw + (size_t)idx * G::N;
+        const BufRsrc twr = make_rsrc(twp, G::N * 16u);
+        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(half_at(y, h)) * G::N;
+        MI355NTT_STAMP2(it, 0);
+        if constexpr (MUL) {
+            // pointwise product with the same half of bhat on the way in, streamed 16 words per lane at a time (as k_polymul15)
+            const BufRsrc brs = make_rsrc(bhat + (size_t)half_at(y, h) * G::N + wave_s * 2048u, 16384u);
+            u64 bb[16];
+            wave_load_rows_half<0>(bb, slice, brs, 0u, 0u);
+            static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                v[r] = FusedMul<HL, NEAR>::mul(v[r], bb[r], p);
+            });
+            wave_load_rows_half<1>(bb, slice, brs, 0u, 0u);
+            static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                v[16 + r] = FusedMul<HL, NEAR>::mul(v[16 + r], bb[r], p);
+            });
+        }
+        MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
+        gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B, MUL && FusedMul<HL, NEAR>::LAZY>(v, twp, twr, fresh_t(), p, primes[idx].twn);
+        MI355NTT_STAMP2(it, 1);
+        wave_transpose_0_to_5(v, slice, fresh_lane_id());
+        MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
+        gs_round<LOGN, HL, 5, 0, NEAR, MI355NTT_PSPLIT_I2, MI355NTT_PRIO_I2B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
+        MI355NTT_STAMP2(it, 2);
+        __syncthreads();                                  // private slices are idle from here on
+        MI355NTT_STAMP2(it, 3);
+        exchange<LOGN, 5, 10>(v, lds, fresh_t());
+        MI355NTT_STAMP2(it, 4);
+        if constexpr (SPLIT != 0) if (h == 0) {
+            // (the exchange ends with a barrier: nobody reads or writes this wave's slice until the next iteration's row loads)
+            const BufRsrc hrs = make_rsrc(poly + G::N, G::N * 8u);
+            split_partner_fetch<0>(hrs, slice, wave_s, fresh_lane_id());
+            split_partner_fetch<1>(hrs, slice, wave_s, fresh_lane_id());
+        }
+        MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
+        gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
+        MI355NTT_STAMP2(it, 5);
+        if constexpr (SPLIT != 0) {
+            if (h == 0) {
+                const BufRsrc lrs = make_rsrc(poly, G::N * 8u), hrs = make_rsrc(poly + G::N, G::N * 8u);
+                const u64 hq = (p.q >> 1) + 1;            // 2^-1 mod q
+                static_for<4>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    // counted waits (hipcc does not order an LDS read behind the LDS-direct load that fills it; loads, stores and
+                    // LDS-direct loads retire in issue order on one counter): phases 0 and 1 behind the last round's twiddle loads --
+                    // everything; phase 2 has 16 + 4 + 16 younger operations behind it, phase 3 has 16 + 16
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if constexpr (c == 2) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+                    else if constexpr (c == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    u64 PV[8];
+                    split_partner_read<c>(PV, slice, fresh_lane_id());
+                    wave_lds_fence();                     // the buffer is free ...
+                    if constexpr (c < 2) split_partner_fetch<c + 2>(hrs, slice, wave_s, fresh_lane_id());     // ... for phase c + 2
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned voff = fresh_t() * 8u;
+                    static_for<8>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, r = 8 * c + i;
+                        const u64 X = v[r], Y = PV[i];
+                        const u64 sm = canon_2q(X + Y, p.q);
+                        const u64 lo = (sm >> 1) + ((sm & 1) ? hq : 0);
+                        const u64 d = X + p.q - Y;
+                        const u64 Tm = Lazy<HL>::EXACT ? mul_shoup2(d, p.si, p.si_p, p.nq) : mul_shoup4m<true>(d, p.si, p.si_p, p.nq);
+                        const u64 hi = canon_2q(reduce_2q_sel<NEAR>(Tm, p), p.q);
+                        v2u32 xl, xh;
+                        xl.x = lo32(lo); xl.y = hi32(lo); xh.x = lo32(hi); xh.y = hi32(hi);
+                        __builtin_amdgcn_raw_buffer_store_b64(xl, lrs, voff, ((unsigned)r << G::B0) * 8u, MI355NTT_INV15_AUX_ST);
+                        __builtin_amdgcn_raw_buffer_store_b64(xh, hrs, voff, ((unsigned)r << G::B0) * 8u, MI355NTT_INV15_AUX_ST);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
+                store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
+            }
+            // next: the lower half of the same polynomial, or the upper half of the next one (ONE load site: two of them meet at
+            // the loop's back edge with different register assignments, and the fix-up spills)
+            const u64* nxt = h == 1 ? poly - G::N : a + (size_t)MI355NTT_POLY_SLOT(half_at(ynext, 1)) * G::N;
+            if (h == 1 || ynext < num) wave_load_rows(v, slice, make_rsrc(nxt + wave_s * 2048u, 16384u), 0u, 0u);
+        } else {
+            store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
+            if (ynext < num)
+                wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+        }
+        MI355NTT_STAMP2(it, 6);
+        if (it < 5) MI355NTT_WGSTAMP(2 + it);
+        it++;
+        if (SPLIT != 0 && h == 1) {
+            h = 0;                       // same polynomial, lower half
+        } else {
+            h = SPLIT ? 1u : 0u;
+            y = ynext;
+            ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep);
+        }
     }
     MI355NTT_STAMP_FLUSH
     MI355NTT_WGSTAMP(7);
@@ -765,6 +934,8 @@ MI355NTT_DECLARE_SIZE(13)
 MI355NTT_DECLARE_SIZE(14)
 MI355NTT_DECLARE_SIZE(15)
 bool fast_fwd_split_ok_15(unsigned num);                  // (kernels_fast_n16.hip)
+hipError_t fast_inv_split_16(int hl, u64* d_a, const u64* d_bhat, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,
+                             unsigned base, hipStream_t s);       // (d_bhat: null, or the pointwise factor applied on the way in)
 hipError_t fast_fwd_split_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                              hipStream_t s);
 

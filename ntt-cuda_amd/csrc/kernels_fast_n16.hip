@@ -5,7 +5,7 @@
 
 namespace mi355ntt {
 
-// n = 2^16 forward on a 2^15 table set: one launch, each workgroup transforms both halves of its polynomials (coupling stage fused)
+// n = 2^16 forward / inverse on a 2^15 table set: one launch, each workgroup transforms both halves of its polynomials (coupling stage fused)
 static bool fwd_split_ok(unsigned num) { return !use_latency_path<15>(2 * num, false); }
 static hipError_t launch_fwd_split16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                                      hipStream_t s)
@@ -21,7 +21,27 @@ static hipError_t launch_fwd_split16(int hl, u64* d_a, const TwPair* tw, const P
     return hipGetLastError();
 }
 
+static hipError_t launch_inv_split16(int hl, u64* d_a, const u64* d_bhat, const TwPair* tw, const PrimeDev* pr, unsigned num,
+                                     unsigned division, unsigned base, hipStream_t s)
+{
+#ifndef MI355NTT_ONLY_HL4N
+    dim3 g(persistent_grid<15>(num)), b(1024);
+    dispatch_class(hl, [&](auto hc, auto nc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr bool NR = decltype(nc)::value;
+        if (d_bhat) k_inverse15_split<H, NR, true><<<g, b, 0, s>>>(d_a, d_bhat, tw, pr, division, base, num);
+        else k_inverse15_split<H, NR, false><<<g, b, 0, s>>>(d_a, nullptr, tw, pr, division, base, num);
+    });
+#endif
+    return hipGetLastError();
+}
+
 bool fast_fwd_split_ok_15(unsigned num) { return fwd_split_ok(num); }
+hipError_t fast_inv_split_16(int hl, u64* d_a, const u64* d_bhat, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,
+                             unsigned base, hipStream_t s)
+{
+    return launch_inv_split16(hl, d_a, d_bhat, tw, pr, num, division, base, s);
+}
 hipError_t fast_fwd_split_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                              hipStream_t s)
 {

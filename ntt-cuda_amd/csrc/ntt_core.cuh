@@ -115,7 +115,8 @@ struct TwPair {       // {w, floor(w * 2^64 / q)}
 // Per-prime constants, read with scalar loads (replaces __constant__ q_cons/mu_cons/q_bit_cons).
 struct PrimeDev {
     u64 q, nq;        // modulus and 2^64 - q
-    u64 rsv0_, rsv1_; // (n^-1 and its companion lived here until round 3: now twn[0])
+    u64 si, si_p;     // n = 2^16 contexts only: psi^-bitrev(1) / 2 of the full-size table (the last GS stage, which couples the halves
+                      // and halves once more) and its Shoup companion (k_inverse15, SPLIT); else 0
     u64 sf, sf_p;     // n = 2^16 contexts only (two half-size transforms per polynomial, capi.cpp): the twiddle of the stage that
                       // couples the halves, psi^bitrev(1) of the full-size table, and its Shoup companion (k_forward15, SPLIT)
     u64 mu;           // Barrett mu = floor(2^(2k)/q), reference convention (pointwise products)

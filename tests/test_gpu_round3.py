@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def dev(native, a):
+    return native.to_device(a)
+
+
 def host(native, t):
     import torch
     torch.cuda.synchronize()
@@ -124,6 +128,76 @@ def test_small_batch_kernels_equal_the_persistent_ones(native, gpu, num):
     words for forward, inverse and the fused product on either side of every switching point of use_latency_path."""
     outs = [_paths_child(32768, num, force) for force in ("100000", "0", None)]
     assert outs[0] == outs[1] == outs[2], outs
+
+
+def _psi_for(q, n):
+    for x in range(2, 1000):
+        psi = pow(x, (q - 1) // (2 * n), q)
+        if pow(psi, n, q) == q - 1:
+            return psi
+    raise AssertionError("no 2n-th root found")
+
+
+# primes = 1 mod 2^17 of every kernel form (headroom class x near-2^k / general): n = 2^16 runs on the n = 2^15 kernels
+N16_FORMS = {
+    "hl6-near": [P.Q55[3]],
+    "hl6-general": [P.GENERAL_PRIMES[57][0]],
+    "hl4-near": P.Q60[:3],
+    "hl4-general": [818574268271558657, P.Q60[0]],
+    "hl2-near": [P.EDGE_PRIMES[62][0], P.EDGE_PRIMES[61][0]],
+    "hl2-general": [3827699395297935361, P.Q60[1]],
+}
+
+
+@pytest.mark.parametrize("form", sorted(N16_FORMS))
+@pytest.mark.parametrize("num", [100, 150, 300])
+def test_n65536_fused_coupling_launches_match_oracle(native, oracle, gpu, form, num):
+    """n = 2^16 (the reference's largest ring degree) as two half-size transforms per polynomial.  From one
+    half per CU up (100 and 300 polynomials; 300 is more than one polynomial per workgroup) the stage that couples the
+    halves is fused into the single launch (k_forward15 SPLIT: in the lower half's loads; k_inverse15_split: behind the lower
+    half's last round, partner rows through LDS-direct loads); 150 polynomials fall into the small-batch window and run the
+    stage as a launch of its own.  Every kernel form, forward and inverse against the oracle on sampled polynomials with
+    adversarial coefficients, the round trip over the whole batch, and the fused product (the pointwise factor multiplied
+    in on the inverse launch's row loads)."""
+    n = 65536
+    qs = N16_FORMS[form]
+    psis = [_psi_for(q, n) for q in qs]
+    Pn = len(qs)
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    assert not ctx.uses_literal_kernels
+    a = oracle.synth_batch(n, num, qs, 4242).reshape(num, n)
+    b = oracle.synth_batch(n, num, qs, 77).reshape(num, n)
+    for y in range(min(num, 2 * Pn)):
+        q = qs[y % Pn]
+        for arr in (a, b):
+            arr[y, :8] = [0, 1, q - 1, q - 2, q - 1, 0, q - 1, 1]
+            arr[y, n // 2 - 2: n // 2 + 2] = [q - 1, 0, q - 1, q - 1]      # either side of the boundary between the halves
+            arr[y, n - 4:] = [q - 1, q - 1, 0, q - 2]
+            arr[y, 40000:40000 + 64] = q - 1
+    sample = sorted(set(list(range(min(num, 2 * Pn))) + [num // 2, num - 2, num - 1] + ([255, 256, 257] if num > 257 else [])))
+    d_a, d_b = dev(native, a), dev(native, b)
+    ctx.forward_batch(d_a, num)
+    A = host(native, d_a).reshape(num, n)
+    for y in sample:
+        assert np.array_equal(A[y], oracle.forward(a[y], prm, y % Pn)), (form, "forward", y)
+    ctx.inverse_batch(d_b, num)                       # (any words below q are a valid input)
+    Bi = host(native, d_b).reshape(num, n)
+    for y in sample:
+        assert np.array_equal(Bi[y], oracle.inverse(b[y], prm, y % Pn)), (form, "inverse", y)
+    ctx.inverse_batch(d_a, num)
+    assert np.array_equal(host(native, d_a).reshape(num, n), a)
+    # the fused product: forward launch + inverse launch with the pointwise factor multiplied in on its row loads
+    d_bh = dev(native, b)
+    ctx.forward_batch(d_bh, num)
+    Bh = host(native, d_bh).reshape(num, n)
+    ctx.polymul_batch(d_a, d_bh, num)
+    F = host(native, d_a).reshape(num, n)
+    for y in sample:
+        one = oracle.Params(n, [qs[y % Pn]], [psis[y % Pn]], tables=False)
+        want = oracle.inverse(oracle.pointwise_batch(A[y], Bh[y], one).reshape(-1), prm, y % Pn)
+        assert np.array_equal(F[y], want), (form, "polymul", y)
+    ctx.close()
 
 
 @pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
