@@ -271,8 +271,8 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 // The fused coupling stage of SPLIT = 1 reads the partner half through the wave's private LDS slice: `buffer_load_dwordx4 ... lds`
 // (LDS-direct: the data never touches a VGPR; lane L's 16 bytes land at M0 + 16 L whatever its global offset -- probed on the
 // hardware, tools/probe/lds_direct.hip) moves two 512-byte partner rows per instruction, lanes 0..31 the row r and lanes 32..63 the
-// row r + 1 of this wave's 64 columns.  Four phases of eight rows, double-buffered in the slice's first 8 KiB: phase 0 is
-// requested at the tail of the previous iteration, phase c + 1 while phase c is multiplied.  (Through registers, eight partner
+// row r + 1 of this wave's 64 columns.  Four phases of eight rows, double-buffered in the slice's first 8 KiB: phases 0 and 1 are
+// requested at the tail of the previous iteration, phase c + 2 as soon as phase c has been read out.  (Through registers, eight partner
 // loads per thread at a time, the stage cost 24 us per polynomial -- four exposed HBM latencies: r03 first version.)
 typedef __attribute__((address_space(3))) void* LdsPtr;
 template <int PH>
@@ -325,8 +325,11 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     [[maybe_unused]] unsigned h = 0;
     auto half_of = [](unsigned yy, unsigned hh) { return SPLIT ? 2 * yy + hh : yy; };
     load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(y, 0)) * G::N, fresh_t());
-    if constexpr (SPLIT != 0)
-        split_partner_fetch<0>(make_rsrc(a + (size_t)(half_of(y, 0) + 1) * G::N, G::N * 8u), lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
+    if constexpr (SPLIT != 0) {
+        const BufRsrc hrs = make_rsrc(a + (size_t)(half_of(y, 0) + 1) * G::N, G::N * 8u);
+        split_partner_fetch<0>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
+        split_partner_fetch<1>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
+    }
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
@@ -342,24 +345,27 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
         u64* poly = a + (size_t)MI355NTT_POLY_SLOT(half_of(y, h)) * G::N;
         if constexpr (SPLIT != 0) if (h == 0) {
-            // the stage that couples the halves, eight partner rows at a time (phase c + 1 in flight while phase c is multiplied;
-            // phase 0 was requested together with this polynomial's own loads, at the tail of the previous iteration)
+            // the stage that couples the halves, eight partner rows at a time (phases 0 and 1 were requested together with this
+            // polynomial's own loads, at the tail of the previous iteration; phase c + 2 goes out as soon as phase c is read)
             const BufRsrc hrs = make_rsrc(poly + G::N, G::N * 8u);
             u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
             const u64 cq = (u64)Lazy<HL>::TQ * p.q;
             static_for<4>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                if constexpr (c < 3) split_partner_fetch<c + 1>(hrs, slice, wave_s, fresh_lane_id());     // (buffer (c + 1) & 1: read out in phase c - 1)
                 // hipcc does not order an LDS read behind the LDS-direct load that fills it: counted wait for phase c's four
-                // loads -- behind them in the queue are phase c - 1's eight stores and phase c + 1's four loads (loads, stores and
-                // LDS-direct loads retire in issue order on one counter)
+                // loads (loads, stores and LDS-direct loads retire in issue order on one counter).  Younger than them in the
+                // queue: phase 1's loads (c = 0); phase 2's loads and phase 0's eight stores (c = 1); those, phase 3's loads
+                // and phase 1's stores (c = 2); the stores of phases 1 and 2 (c = 3)
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (c == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if constexpr (c < 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (c == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr (c == 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 u64 PV[8];
                 split_partner_read<c>(PV, slice, fresh_lane_id());
-                wave_lds_fence();                         // the buffer is free for phase c + 2 before anything is requested into it
+                wave_lds_fence();                         // the buffer is free ...
+                if constexpr (c < 2) split_partner_fetch<c + 2>(hrs, slice, wave_s, fresh_lane_id());     // ... for phase c + 2
+                __builtin_amdgcn_sched_barrier(0);
                 const unsigned voff = fresh_t() * 8u;
                 static_for<8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, r = 8 * c + i;
@@ -400,7 +406,9 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
                 load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly + G::N, fresh_t());
             } else if (ynext < num) {
                 load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(ynext, 0)) * G::N, fresh_t());
-                split_partner_fetch<0>(make_rsrc(a + (size_t)(half_of(ynext, 0) + 1) * G::N, G::N * 8u), lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
+                const BufRsrc hrs = make_rsrc(a + (size_t)(half_of(ynext, 0) + 1) * G::N, G::N * 8u);
+                split_partner_fetch<0>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
+                split_partner_fetch<1>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
             }
         } else {
             if (ynext < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N, fresh_t());
