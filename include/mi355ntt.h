@@ -113,6 +113,14 @@ const mi355ntt_u64* mi355ntt_ctx_psiinv_tables(const mi355ntt_ctx* ctx);
  * hipStreamBeginCapture and hipStreamEndCapture and the resulting hipGraph replayed (tools/lat_bench.cpp does, and checks
  * the results).  Not capture-safe: context / BFV creation and destruction, mi355ntt_ctx_probed_clock_mhz, and the
  * FIRST call of a raw-parameter entry point with a given table (it derives and caches a context: see below).
+ *
+ * n = 65536, batches from about one half-size transform per CU up: the forward transform runs two cooperating workgroups per
+ * polynomial (they read each other's half of the input and exchange one "have read it" flag before storing in place; grid <=
+ * one workgroup per CU, so it is resident as a whole).  The flag buffer is per device and belongs to one stream at a time: a
+ * call on another stream while such a launch is still in flight, and any call on a capturing stream, runs the single-workgroup
+ * launch instead (same words, ~10 % slower); the hand-over costs one hipEventRecord / hipEventQuery on the host.  A workgroup
+ * whose partner does not become resident within tens of seconds aborts the kernel (hipErrorLaunchFailure at the next
+ * synchronisation) rather than hang: that can only happen when another workload holds the device's CUs indefinitely.
  * ---------------------------------------------------------------------------------------------- */
 /* forwardNTT (ntt_60bit.cuh:314-348): one polynomial, prime prime_idx */
 int mi355ntt_forward(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream stream);

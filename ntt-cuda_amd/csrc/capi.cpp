@@ -230,7 +230,9 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
             for (unsigned h = 0; h < 2; h++) {
                 const unsigned v = 2 * i + h;
                 vprime[v] = c->prime[i];
-                split_fwd[v] = hp[(size_t)i * n + 1];                               // psi^bitrev(1): stage 1 of the full-size transform
+                // psi^bitrev(1): stage 1 of the full-size transform (k_forward15 SPLIT reads the lower half's); negated for the
+                // upper half, which forms U - V w as U + V (-w) (k_forward15_pair)
+                split_fwd[v] = h ? c->prime[i].q - hp[(size_t)i * n + 1] : hp[(size_t)i * n + 1];
                 split_inv[v] = hi[(size_t)i * n + 1];                               // psi^-bitrev(1): its last GS stage
                 vprime[v].ninv = modinv(h_n % c->prime[i].q, c->prime[i].q);       // the half-size transform scales by (n/2)^-1 ...
                 u64* tp = vp.data() + (size_t)v * h_n;                              // ... and the last GS stage halves once more

@@ -9,7 +9,9 @@
 #include "ntt_core.cuh"
 #include "kernels_fast_impl.cuh"
 
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace mi355ntt {
@@ -69,6 +71,74 @@ ModSet shifted(const ModSet& m, unsigned base, unsigned division)
     return r;
 }
 
+// ---- the device's pair flags (k_forward15_pair) --------------------------------------------------
+// One zeroed flag buffer per device, owned by ONE stream at a time: a launch of the pair kernel is followed by an event on its
+// stream, and another stream gets the buffer only once that event has completed (until then it runs the single-workgroup form).
+// So the pair kernels in flight on a device are ordered on one stream: their flags never mix, and workgroups spinning for a
+// partner can only be waiting for workgroups of their own launch that are next in line for a CU.  A capturing stream never takes
+// it (a graph may replay next to anything).  Created with the first n = 2^16 context on the device (fast_tables_create: no
+// allocation at call time).
+struct PairSlot {
+    unsigned* d_flags = nullptr;
+    hipEvent_t done = nullptr;
+    hipStream_t owner = nullptr;
+    bool in_flight = false;
+};
+constexpr int kMaxDevices = 64;
+PairSlot g_pair[kMaxDevices];
+std::mutex g_pair_mutex;
+
+hipError_t pair_init_current_device()
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipSuccess;           // (no slot: the single-workgroup form runs)
+    std::lock_guard<std::mutex> lock(g_pair_mutex);
+    PairSlot& p = g_pair[dev];
+    if (p.d_flags) return hipSuccess;
+    unsigned* f = nullptr;
+    if ((e = hipMalloc((void**)&f, kPairFlagWords * sizeof(unsigned))) != hipSuccess) return e;
+    if ((e = hipMemset(f, 0, kPairFlagWords * sizeof(unsigned))) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming)) != hipSuccess) {
+        (void)hipFree(f);
+        return e;
+    }
+    p.d_flags = f;
+    return hipSuccess;
+}
+
+// the slot when stream s may launch the pair kernel now, else null; pair_release records the launch
+PairSlot* pair_acquire(hipStream_t s)
+{
+    static const bool off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;      // (A/B measurements)
+    if (off) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    g_pair_mutex.lock();
+    PairSlot& p = g_pair[dev];
+    bool ok = p.d_flags != nullptr;
+    if (ok && p.in_flight && p.owner != s) {
+        if (hipEventQuery(p.done) == hipSuccess) p.in_flight = false;
+        else ok = false;
+    }
+    if (!ok) {
+        (void)hipGetLastError();                                    // (hipErrorNotReady of the query is not an error of this call)
+        g_pair_mutex.unlock();
+        return nullptr;
+    }
+    p.owner = s;
+    return &p;                                                      // (mutex held until pair_release: launch and event stay together)
+}
+void pair_release(PairSlot* p, hipStream_t s)
+{
+    p->in_flight = (hipEventRecord(p->done, s) == hipSuccess);
+    if (!p->in_flight) (void)hipStreamSynchronize(s);               // (no event: be sure instead)
+    g_pair_mutex.unlock();
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -124,6 +194,10 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         if (!near_ok) all_near = false;
     }
     if (all_near) t->hl |= 16;
+    if (split_fwd) {                                     // (n = 2^16 contexts: the device's pair flags exist before the first call)
+        const hipError_t pe = pair_init_current_device();
+        if (pe != hipSuccess) return pe;
+    }
     const size_t words = (size_t)num_primes * n;
     // device layout: stage blocks transposed per round (ntt_core.cuh, tw_dev_index); entry 0 is never read
     std::vector<TwPair> hf(words), hi(words);
@@ -229,6 +303,13 @@ hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsig
 bool fast_forward_split16_ok(const FastTables& t, unsigned num) { return t.log_n == 15 && fast_fwd_split_ok_15(num); }
 hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
+    // two workgroups per polynomial (k_forward15_pair: 1 x / 1 x traffic) when this stream may own the device's pair flags
+    if (PairSlot* slot = fast_fwd_pair_ok_16(t.hl) ? pair_acquire(s) : nullptr) {
+        const hipError_t e = fast_fwd_pair_16(t.hl, d_a, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const PrimeDev*>(t.d_primes),
+                                              num, division, prime_base, s, slot->d_flags);
+        pair_release(slot, s);
+        return e;
+    }
     return fast_fwd_split_16(t.hl, d_a, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const PrimeDev*>(t.d_primes), num,
                              division, prime_base, s);
 }

@@ -428,6 +428,130 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     MI355NTT_WGSTAMP(7);
 }
 
+// n = 2^16 forward, cooperative: TWO workgroups per polynomial, one per output half (role 0 = lower, 1 = upper).  Both read the
+// whole polynomial the same way -- the lower half U into registers, the upper half V through the LDS slices (split_partner_fetch)
+// -- and form U + V w' for the stage that couples the halves: w' = psi^bitrev(1) for role 0, its negative for role 1 (the `sf` of
+// the role's virtual prime, capi.cpp), so the two roles run the same code.  Nothing is written before the rounds, so the
+// polynomial comes from HBM once (the second reader of a pair -- same XCD, see the mapping -- hits what the first has just pulled
+// through the L2) and is written once: 1 x / 1 x instead of the 1.5 x / 1.5 x of the single-workgroup form (k_forward15 SPLIT).
+// The transform is in place, so a workgroup must not store its half of the result before the partner has READ the input
+// underneath: one flag per workgroup, `flags[2 pair + role]` = number of polynomials this workgroup has read completely (written
+// after the barrier behind round 1, polled before the row store ~25 us later; agent scope, relaxed: the protected accesses are
+// loads that have returned before the flag is written and stores issued after it is seen).  The flags are zero between launches
+// (each workgroup clears the one it polls on exit); the buffer belongs to one stream at a time (kernels_fast.hip).  Grid: an even
+// number of workgroups, all resident (one per CU).
+template <int HL, bool NEAR>
+__global__ void __launch_bounds__(1024, 4)
+k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
+                 unsigned prime_base, unsigned num, unsigned* __restrict__ flags)
+{
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
+    constexpr int LOGN = 15;
+    using G = Geo<LOGN>;
+    __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+s"(wave_s));
+    auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
+    u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
+    // workgroups are dealt round-robin over the 8 XCDs: w and w + 8 share an L2 (when the grid is a multiple of 16)
+    const unsigned w = blockIdx.x;
+    const bool xcd_map = (gridDim.x & 15u) == 0;
+    unsigned role = __builtin_amdgcn_readfirstlane(xcd_map ? (w >> 3) & 1u : w & 1u);
+    unsigned pair = __builtin_amdgcn_readfirstlane(xcd_map ? ((w >> 4) << 3) | (w & 7u) : w >> 1);
+    asm volatile("" : "+s"(role), "+s"(pair));
+    const unsigned npairs = gridDim.x >> 1;
+    // (flag addresses are rebuilt from SGPRs where they are used: as 64-bit pointers they live in VGPRs across the loop -- spills)
+    auto flag_at = [&](unsigned which) {
+        unsigned f = 2 * pair + which;
+        asm volatile("" : "+s"(f));
+        return flags + f;
+    };
+    unsigned y = pair;
+    if (y >= num) return;
+    {
+        const unsigned ph = (w >> 4) & 7u, units = ph * (num > npairs ? (unsigned)MI355NTT_STAGGER_FWD_MULTI : (unsigned)MI355NTT_STAGGER_FWD);
+        for (unsigned i = 0; i < units; i++) __builtin_amdgcn_s_sleep(32);
+    }
+    u64 v[32];
+    auto request = [&](unsigned yy) {                     // everything of polynomial yy: U into registers, V (phases 0, 1) into the slice
+        load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(2 * yy) * G::N, fresh_t());
+        const BufRsrc hrs = make_rsrc(a + (size_t)(2 * yy + 1u) * G::N, G::N * 8u);
+        split_partner_fetch<0>(hrs, slice, wave_s, fresh_lane_id());
+        split_partner_fetch<1>(hrs, slice, wave_s, fresh_lane_id());
+    };
+    unsigned ymod = __builtin_amdgcn_readfirstlane(pair % division), ystep = __builtin_amdgcn_readfirstlane(npairs % division);
+    asm volatile("" : "+s"(ymod), "+s"(ystep));
+    unsigned it = 0;
+    // (the loop is entered one pass early, with nothing to transform yet: ONE request site -- two of them, in front of the loop and
+    // at its tail, meet at the back edge with different register assignments, and the fix-up parks loaded words in scratch behind
+    // a full wait)
+    bool have = false;
+    unsigned ynext = y;
+    for (;;) {
+        if (have) {
+        const unsigned idx = 2 * (prime_base + ymod) + role;
+        const PrimeDev p = primes[idx];
+        const TwPair* twp = tw + (size_t)idx * G::N;
+        const BufRsrc twr = make_rsrc(twp, G::N * 16u);
+        {
+            // the stage that couples the halves, eight rows of V at a time (phases 0 and 1 were requested together with U; phase
+            // c + 2 goes out as soon as phase c is read).  Counted waits, see k_forward15: younger than phase c's loads are the
+            // four of phase c + 1 (none behind phase 3)
+            const BufRsrc hrs = make_rsrc(a + (size_t)(2 * y + 1u) * G::N, G::N * 8u);
+            static_for<4>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                u64 PV[8];
+                split_partner_read<c>(PV, slice, fresh_lane_id());
+                wave_lds_fence();                         // the buffer is free ...
+                if constexpr (c < 2) split_partner_fetch<c + 2>(hrs, slice, wave_s, fresh_lane_id());     // ... for phase c + 2
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, r = 8 * c + i;
+                    const u64 Tm = Lazy<HL>::EXACT ? mul_shoup2(PV[i], p.sf, p.sf_p, p.nq) : mul_shoup4m<true>(PV[i], p.sf, p.sf_p, p.nq);
+                    v[r] = reduce_2q_sel<NEAR>(v[r] + Tm, p);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
+        ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, 0u, p);
+        __syncthreads();                                  // every wave has left its private slice -- and holds its share of the input
+        if (threadIdx.x == 0) __hip_atomic_store(flag_at(role), it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        exchange<LOGN, 10, 5>(v, lds, fresh_t());
+        MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
+        ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, fresh_t(), p);
+        wave_transpose_5_to_0(v, slice, fresh_lane_id());
+        MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
+        ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
+        // the partner has read the input under this result?  (long since, normally.  A partner that never shows up -- seconds --
+        // means the grid is not resident as a whole, which the launch rules exclude: abort the kernel, loudly, rather than hang
+        // or store over words the partner still needs)
+        {
+            unsigned spin = 0;
+            unsigned* const partner_flag = flag_at(1u - role);
+            while (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spin == (1u << 25)) __builtin_trap();
+            }
+        }
+        wave_store_rows(v, slice, make_rsrc(a + (size_t)(2 * y + role) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+        it++;
+        ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep);
+        }
+        if (ynext >= num) break;
+        request(ynext);
+        have = true;
+        y = ynext;
+        ynext = y + npairs;
+    }
+    __syncthreads();                                      // every wave has polled for the last time:
+    if (threadIdx.x == 0) __hip_atomic_store(flag_at(1u - role), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero between launches
+}
+
 template <int HL, bool NEAR>
 __global__ void __launch_bounds__(1024, 4)
 k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
@@ -942,6 +1066,10 @@ MI355NTT_DECLARE_SIZE(13)
 MI355NTT_DECLARE_SIZE(14)
 MI355NTT_DECLARE_SIZE(15)
 bool fast_fwd_split_ok_15(unsigned num);                  // (kernels_fast_n16.hip)
+hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
+                            hipStream_t s, unsigned* d_flags);      // (two workgroups per polynomial; d_flags: kPairFlagWords zeroed words)
+constexpr unsigned kPairFlagWords = 2048;
+bool fast_fwd_pair_ok_16(int hl);                         // (headroom classes 4 and 6)
 hipError_t fast_inv_split_16(int hl, u64* d_a, const u64* d_bhat, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,
                              unsigned base, hipStream_t s);       // (d_bhat: null, or the pointwise factor applied on the way in)
 hipError_t fast_fwd_split_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,

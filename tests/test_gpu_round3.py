@@ -200,6 +200,58 @@ def test_n65536_fused_coupling_launches_match_oracle(native, oracle, gpu, form, 
     ctx.close()
 
 
+def test_n65536_pair_launches_share_the_device_between_streams_and_graphs(native, oracle, gpu):
+    """The n = 2^16 forward transform of a large batch runs two workgroups per polynomial that hand each other a flag
+    (k_forward15_pair); the device's flag buffer belongs to one stream at a time, a second stream with work in flight and a
+    capturing stream get the single-workgroup launch.  Same words on every route: two streams interleaved without waiting for
+    each other, and a captured graph replayed twice (forward, inverse, forward), all against the oracle / the round trip."""
+    import torch
+    n, num = 65536, 260
+    qs = P.Q60[:2]
+    psis = [_psi_for(q, n) for q in qs]
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = oracle.synth_batch(n, num, qs, 2024).reshape(num, n)
+    b = oracle.synth_batch(n, num, qs, 2025).reshape(num, n)
+    sample = [0, 1, 127, 128, 129, 255, 256, 259]
+    want_a = {y: oracle.forward(a[y], prm, y % 2) for y in sample}
+    want_b = {y: oracle.forward(b[y], prm, y % 2) for y in sample}
+    d_a, d_b = dev(native, a), dev(native, b)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):                                # forward, inverse, forward, ... on both streams, nobody waits
+        ctx.forward_batch(d_a, num, stream=s1)
+        ctx.forward_batch(d_b, num, stream=s2)
+        ctx.inverse_batch(d_a, num, stream=s1)
+        ctx.inverse_batch(d_b, num, stream=s2)
+    ctx.forward_batch(d_a, num, stream=s1)
+    ctx.forward_batch(d_b, num, stream=s2)
+    torch.cuda.synchronize()
+    A, B = host(native, d_a).reshape(num, n), host(native, d_b).reshape(num, n)
+    for y in sample:
+        assert np.array_equal(A[y], want_a[y]), ("stream 1", y)
+        assert np.array_equal(B[y], want_b[y]), ("stream 2", y)
+    # captured: forward, inverse, forward in one graph
+    d_c = dev(native, a)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=cs):
+        ctx.forward_batch(d_c, num)
+        ctx.inverse_batch(d_c, num)
+        ctx.forward_batch(d_c, num)
+    for rep in range(2):
+        d_c.copy_(dev(native, a))
+        g.replay()
+        ctx.forward_batch(d_b, num)                   # (a pair launch next to the replay, other stream)
+        torch.cuda.synchronize()
+        C = host(native, d_c).reshape(num, n)
+        for y in sample:
+            assert np.array_equal(C[y], want_a[y]), ("graph", rep, y)
+        ctx.inverse_batch(d_b, num)
+    ctx.close()
+
+
 @pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
 @pytest.mark.parametrize("num", [1, 5, 300])
 def test_small_batch_kernels_at_every_ring_degree(native, oracle, gpu, n, num):
