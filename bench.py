@@ -595,7 +595,45 @@ def main():
                 cpp_lat = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as exc:
                 cpp_lat = {"error": repr(exc)}
+        # n = 2^16 (the reference's largest ring degree, parameter.h): two half-size transforms per polynomial in ONE launch each
+        # (kernels_fast_n16.hip); 512 polynomials = the same 256 MiB as the headline batch
+        n16 = None
+        try:
+            q16 = Q60[0]
+            psi16 = next(pw for pw in (pow(x, (q16 - 1) // (2 * 65536), q16) for x in range(2, 1000)) if pow(pw, 65536, q16) == q16 - 1)
+            c16 = ntt.NTTContext(65536, [q16], [psi16])
+            a16, b16 = synth(torch, 512, 65536, [q16], dev, seed=5), synth(torch, 512, 65536, [q16], dev, seed=6)
+            ref16 = a16.clone()
+
+            def rate16(fn):
+                for _ in range(60):
+                    fn()
+                e0.record()
+                for _ in range(40):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 40
+
+            f16 = rate16(lambda: c16.forward_batch(a16, 512))          # (100 forwards in a row: still residues, any words below q do)
+            a16.copy_(ref16)
+            c16.forward_batch(a16, 512)
+            c16.inverse_batch(a16, 512)
+            torch.cuda.synchronize()
+            ok16 = bool(torch.equal(a16, ref16))
+            i16 = rate16(lambda: c16.inverse_batch(a16, 512))
+            c16.forward_batch(b16, 512)
+            m16 = rate16(lambda: c16.polymul_batch(a16, b16, 512))
+            bytes16 = 512 * 65536 * 16
+            n16 = {"batch": 512, "forward_ms": f16, "inverse_ms": i16, "fused_product_ms": m16, "round_trip_ok": ok16,
+                   "forward_algorithmic_GBps": bytes16 / (f16 * 1e-3) / 1e9, "inverse_algorithmic_GBps": bytes16 / (i16 * 1e-3) / 1e9,
+                   "how": "forward: two cooperating workgroups per polynomial (k_forward15_pair); inverse / product: one workgroup per polynomial, coupling stage fused (k_inverse15_split)"}
+            c16.close()
+            del a16, b16, ref16
+        except Exception as exc:            # never let an optional leg break the contract line
+            n16 = {"error": repr(exc)}
         out["extras"] = {"config2_fused_polymul_batch256_per_s": 256 / (mul_ms * 1e-3), "config2_fused_polymul_ms": mul_ms,
+                         "n65536_batch512": n16,
                          "fused_polymul_headline_batch": polymul,
                          "latency_compiled_cpp": cpp_lat,
                          "config1_batch1_fwd_inv_pair_us": pair_us, "config1_batch1_forward_us": fwd_us,
