@@ -84,7 +84,7 @@ static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, uns
     if (c->literal) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides behind the lower halves' last round (1.5 passes over memory instead of 2)
-        if (fast_forward_split16_ok(c->fast, num)) return fast_inverse_split16(c->fast, d_a, num, division, base, s);
+        if (fast_inverse_split16_ok(c->fast, num, false)) return fast_inverse_split16(c->fast, d_a, num, division, base, s);
         hipError_t e = fast_inverse_batch(c->fast, d_a, 2 * num, 2 * division, 2 * base, s);
         if (e != hipSuccess) return e;
         return compat_gs_stage(d_a, c->n, c->d_psiinv + (size_t)base * c->n, 1, num, division, mods_from(c, base, division), s);
@@ -371,7 +371,7 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355
     if (!d_bhat) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
     ON_CTX_DEVICE(c);
-    if (c->split16 && fast_forward_split16_ok(c->fast, num)) {      // n = 2^16, large batch: the product rides in the inverse launch's loads
+    if (c->split16 && fast_inverse_split16_ok(c->fast, num, true)) {      // n = 2^16, large batch: the product rides in the inverse launch's loads
         HIP_TRY(fast_forward_split16(c->fast, d_a, num, division, 0, (hipStream_t)s));
         HIP_TRY(fast_inverse_split16(c->fast, d_a, num, division, 0, (hipStream_t)s, d_bhat));
         return MI355NTT_OK;

@@ -88,6 +88,7 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
 // n = 2^16 forward as two launches over half-size transforms, the coupling stage fused into the first (1.5 instead of 2 passes
 // over memory); _ok: the batch is large enough for the persistent kernels
 bool fast_forward_split16_ok(const FastTables& t, unsigned num);
+bool fast_inverse_split16_ok(const FastTables& t, unsigned num, bool product);   // (product: forward + inverse-with-factor launches)
 hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);
 // (same condition; d_bhat: null, or a factor in the NTT domain -- one polynomial per polynomial of d_a -- multiplied in on the way in)
 hipError_t fast_inverse_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s,

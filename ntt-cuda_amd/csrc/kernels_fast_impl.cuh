@@ -1065,7 +1065,7 @@ MI355NTT_DECLARE_SIZE(12)
 MI355NTT_DECLARE_SIZE(13)
 MI355NTT_DECLARE_SIZE(14)
 MI355NTT_DECLARE_SIZE(15)
-bool fast_fwd_split_ok_15(unsigned num);                  // (kernels_fast_n16.hip)
+bool fast_split_ok_16(unsigned num, int op, bool pair);   // (kernels_fast_n16.hip; op: 0 forward, 1 inverse, 2 fused product)
 hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                             hipStream_t s, unsigned* d_flags);      // (two workgroups per polynomial; d_flags: kPairFlagWords zeroed words)
 constexpr unsigned kPairFlagWords = 2048;

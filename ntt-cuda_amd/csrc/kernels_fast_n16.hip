@@ -6,7 +6,20 @@
 namespace mi355ntt {
 
 // n = 2^16 forward / inverse on a 2^15 table set: one launch, each workgroup transforms both halves of its polynomials (coupling stage fused)
-static bool fwd_split_ok(unsigned num) { return !use_latency_path<15>(2 * num, false); }
+// From how many polynomials on the one-launch forms win over the stage launch + small-batch kernels (tools/crossover16.py,
+// profiles/r03_n65536_crossover.txt): the pair launch runs 2 num workgroups, flat 42 ... 52 us up to 128 polynomials; the
+// single-workgroup forms transform both halves one after the other, flat 80 us up to 256.  No second window as at n = 2^15:
+// up to 256 polynomials every workgroup makes one pass.  op: 0 forward (pair form available or not), 1 inverse, 2 fused product.
+static bool split_ok(unsigned num, int op, bool pair)
+{
+    static const long forced = [] {
+        const char* e = std::getenv("MI355NTT_LATENCY_PATH_MAX");      // (tuning / tests, as use_latency_path: counts half-size transforms)
+        return e ? (long)std::strtoul(e, nullptr, 10) : -1L;
+    }();
+    if (forced >= 0) return 2ul * num > (unsigned long)forced;
+    const unsigned from = op == 0 ? (pair ? 72u : 120u) : op == 1 ? 120u : 96u;
+    return num >= from;
+}
 static hipError_t launch_fwd_split16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                                      hipStream_t s)
 {
@@ -58,7 +71,7 @@ hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* 
     return hipGetLastError();
 }
 
-bool fast_fwd_split_ok_15(unsigned num) { return fwd_split_ok(num); }
+bool fast_split_ok_16(unsigned num, int op, bool pair) { return split_ok(num, op, pair); }
 bool fast_fwd_pair_ok_16(int hl) { return (hl & 15) >= 4; }
 hipError_t fast_inv_split_16(int hl, u64* d_a, const u64* d_bhat, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,
                              unsigned base, hipStream_t s)

@@ -150,15 +150,16 @@ N16_FORMS = {
 
 
 @pytest.mark.parametrize("form", sorted(N16_FORMS))
-@pytest.mark.parametrize("num", [100, 150, 300])
+@pytest.mark.parametrize("num", [72, 100, 130, 300])
 def test_n65536_fused_coupling_launches_match_oracle(native, oracle, gpu, form, num):
-    """n = 2^16 (the reference's largest ring degree) as two half-size transforms per polynomial.  From one
-    half per CU up (100 and 300 polynomials; 300 is more than one polynomial per workgroup) the stage that couples the
-    halves is fused into the single launch (k_forward15 SPLIT: in the lower half's loads; k_inverse15_split: behind the lower
-    half's last round, partner rows through LDS-direct loads); 150 polynomials fall into the small-batch window and run the
-    stage as a launch of its own.  Every kernel form, forward and inverse against the oracle on sampled polynomials with
-    adversarial coefficients, the round trip over the whole batch, and the fused product (the pointwise factor multiplied
-    in on the inverse launch's row loads)."""
+    """n = 2^16 (the reference's largest ring degree) as two half-size transforms per polynomial.  Large batches
+    run ONE launch per transform with the stage that couples the halves fused in: forward from 72 polynomials (two cooperating
+    workgroups per polynomial, k_forward15_pair; the 61/62-bit classes: one workgroup, k_forward15 SPLIT, from 120), fused
+    product from 96, inverse from 120 (k_inverse15_split, partner rows through LDS-direct loads); below that the stage is a
+    launch of its own around the small-batch kernels.  72 / 100 / 130 / 300 polynomials put the three operations on both
+    sides of their switching points, 130 and 300 give some workgroups a second polynomial.  Every kernel form, forward and
+    inverse against the oracle on sampled polynomials with adversarial coefficients, the round trip over the whole batch, and
+    the fused product (the pointwise factor multiplied in on the inverse launch's row loads)."""
     n = 65536
     qs = N16_FORMS[form]
     psis = [_psi_for(q, n) for q in qs]
