@@ -15,6 +15,8 @@
 //     (Barrett-inexact moduli, hand-made mu, table entries >= q): every stage in LDS (n <= 2^15) or one launch per stage.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -157,6 +159,7 @@ struct Scratch30 {
     u32 ninv, ninv_p;        // m^-1 mod q for the transform size m the kernel runs (n, or n/2 for the split) + companion
     u32 w1n[2], w1n_p[2];    // psiinv-table entry of the last GS stage (index A: 1, or 2 + h for half h) times ninv + companions
     unsigned pad[8];
+    unsigned flags[1024];    // k_ntt30x PAIR: one "have read it" counter per workgroup, zero between launches
     uint2 tw[65536];         // {w, floor(w * 2^32 / q)}
 };
 
@@ -211,6 +214,7 @@ __device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return y *
 // layouts is conflict-free or 2-way).  Thread part and register part of an index occupy disjoint bit fields, so the slot
 // splits into a per-thread base and a compile-time offset per register.
 constexpr unsigned pad32(unsigned i) { return i + (i >> 5); }
+constexpr unsigned kPair30MinPolys = 64;              // (below: the stage launch + one workgroup per half; tools/bench30.py)
 
 template <int BO, int BN>
 __device__ __forceinline__ void exchange32(u32 (&v)[32], u32* img, unsigned t)
@@ -454,8 +458,10 @@ __device__ __forceinline__ void gs_round32(u32 (&v)[32], const uint2* __restrict
     });
 }
 
-template <int LOGN, int RHO>
-__device__ __forceinline__ void fwd_rounds32(u32 (&v)[32], const uint2* tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, u32* img)
+// after_first_exchange: called behind the first workgroup-wide exchange (every wave has passed its barriers, i.e. has finished
+// whatever it did with its inputs in front of round 1)
+template <int LOGN, int RHO, class F>
+__device__ __forceinline__ void fwd_rounds32(u32 (&v)[32], const uint2* tw, BufRsrc twr, unsigned tmul, unsigned t, u32 q, u32* img, F&& after_first_exchange)
 {
     using G = Geo<LOGN>;
     if constexpr (RHO < G::NR) {
@@ -465,9 +471,10 @@ __device__ __forceinline__ void fwd_rounds32(u32 (&v)[32], const uint2* tw, BufR
             constexpr int TOPP = LOGN - 1 - 5 * (RHO - 1);
             constexpr int BP = TOPP - 4 > 0 ? TOPP - 4 : 0;
             exchange32<BP, B>(v, img, t);
+            if constexpr (RHO == 1) after_first_exchange();
         }
         ct_round32<LOGN, B, TOP - B>(v, tw, twr, tmul, t, q);
-        fwd_rounds32<LOGN, RHO + 1>(v, tw, twr, tmul, t, q, img);
+        fwd_rounds32<LOGN, RHO + 1>(v, tw, twr, tmul, t, q, img, after_first_exchange);
     }
 }
 
@@ -500,12 +507,22 @@ __device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufR
 #endif
 // One workgroup of 2^LOGN / 32 threads per polynomial of 2^LOGN words, persistent over the batch.  split: the polynomials
 // are the halves of 2^(LOGN+1)-word polynomials whose first (forward) / last (inverse) stage runs as a stage launch.
-template <int LOGN, bool FWD>
+// PAIR (forward, split: the polynomials are the halves of 2^(LOGN+1)-word polynomials): no stage launch in front.  Two
+// workgroups per full-size polynomial, one per output half (role = the half; on CUs of one XCD when the grid is a multiple of
+// 16), both read the lower half U (prefetch set) and the upper half V (second set, requested behind the last round of the
+// previous polynomial) and enter round 1 with U + V w' -- w' the table's entry 1 for the lower, its negative for the upper
+// half -- so the polynomial is read once from HBM (the second reader hits the L2) and written once, instead of twice each.
+// In place: a workgroup stores only after its partner has read the input underneath -- flags[2 pair + role] counts the
+// polynomials a workgroup has read completely (written behind the first exchange, polled in front of the stores, cleared on
+// exit); the buffer lives in the (device, stream) scratch, the grid is resident as a whole (one workgroup per CU).  As
+// k_forward15_pair of the 60-bit path (kernels_fast_impl.cuh).
+template <int LOGN, bool FWD, bool PAIR = false>
 // (two workgroups of 1024 threads per CU would need 64 VGPRs per thread; without the prefetch set and with twiddle groups
 // of 4 the forward kernel still wants 98 -- measured with a waves-per-SIMD bound of 8 -- so n = 2^15 stays at one)
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)       // 128 VGPRs: four waves per SIMD, i.e. as many workgroups per CU as the LDS image admits
-k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned num, unsigned split)
+k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned num, unsigned split, unsigned* __restrict__ flags)
 {
+    static_assert(!PAIR || FWD, "the pair form exists for the forward transform");
     if (sc->guard[0] == sc->guard[1]) return;            // a table entry >= q: the literal leg transforms the data
     using G = Geo<LOGN>;
     constexpr unsigned n = G::N;
@@ -513,13 +530,28 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
     const unsigned t = threadIdx.x;
     const uint2* tw = sc->tw;
     const BufRsrc twr = make_rsrc(tw, 65536u * 8u);
+    // first half-size polynomial of this workgroup and the distance to its next one
+    [[maybe_unused]] unsigned role = 0, pair = 0;
+    if constexpr (PAIR) {
+        const unsigned w = blockIdx.x;
+        const bool xcd_map = (gridDim.x & 15u) == 0;      // workgroups are dealt round-robin over the 8 XCDs: w and w + 8 share an L2
+        role = __builtin_amdgcn_readfirstlane(xcd_map ? (w >> 3) & 1u : w & 1u);
+        pair = __builtin_amdgcn_readfirstlane(xcd_map ? ((w >> 4) << 3) | (w & 7u) : w >> 1);
+    }
+    const unsigned first = PAIR ? 2 * pair + role : blockIdx.x, stride = gridDim.x;      // (PAIR: an even grid, 2 x pairs)
+    auto flag_at = [&](unsigned which) {                  // (rebuilt from SGPRs at its uses: a pointer kept across the loop is a VGPR pair)
+        unsigned f = __builtin_amdgcn_readfirstlane(2 * pair + which);
+        asm volatile("" : "+s"(f));
+        return flags + f;
+    };
     // the next polynomial's coefficients are loaded into a second register set while the current one is transformed (one
     // workgroup per CU at n = 2^15: nothing else would cover the memory latency)
     // Forward: coalesced 4-byte loads (thread t, register r = word (r << B0) | t, the layout round 1 wants), results leave
     // from layout 0 through the wave-local row staging (16-byte stores); inverse: the mirror image.
     u32 v[32], nx[32];
+    [[maybe_unused]] u32 nv[PAIR ? 32 : 1];
     auto issue_loads = [&](unsigned y, bool real) {
-        const BufRsrc rs = make_rsrc(a + (size_t)y * n, real ? n * 4u : 0u);
+        const BufRsrc rs = make_rsrc(a + (size_t)(PAIR ? y & ~1u : y) * n, real ? n * 4u : 0u);      // (PAIR: the lower half U)
 #if defined(NTT30_NOMEM) || defined(NTT30_NOLOAD)         // timing experiment: no polynomial traffic
         static_for<32>([&](auto rc) { nx[decltype(rc)::value] = (t + decltype(rc)::value + y) & 0xffffu; });
         return;
@@ -529,6 +561,12 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
         else
             issue_row_loads32(nx, rs, t);
     };
+    auto issue_loads_v = [&](unsigned y, bool real) {     // PAIR: the upper half V of the same full-size polynomial
+        if constexpr (PAIR) {
+            const BufRsrc rs = make_rsrc(a + (size_t)(y | 1u) * n, real ? n * 4u : 0u);
+            static_for<32>([&](auto rc) { nv[decltype(rc)::value] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
+        }
+    };
     auto issue_stores = [&](BufRsrc prs) {                // forward: 8 x 16 bytes per thread from layout 0; inverse: 32 x 4 bytes, coalesced layout
         if constexpr (FWD)
             wave_store_rows32(v, img, prs, t);
@@ -537,12 +575,12 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
     };
 #if NTT30_STAGGER > 0
     // every workgroup runs the same schedule; 8 phase groups per XCD start NTT30_STAGGER x 2048 cycles apart
-    if (FWD && gridDim.x >= 256u)
-        for (unsigned i = 0; i < ((blockIdx.x >> 3) & 7u) * NTT30_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
+    if (FWD && gridDim.x >= 256u)                          // (PAIR: partners start together)
+        for (unsigned i = 0; i < ((blockIdx.x >> (PAIR ? 4 : 3)) & 7u) * NTT30_STAGGER; i++) __builtin_amdgcn_s_sleep(32);
 #endif
-    if (blockIdx.x >= num) return;
+    if (first >= num) return;
     if constexpr (NTT30_LDS_TW && LOGN == 15) {          // middle-round twiddles into LDS (read only after the first exchange's barriers)
-        const unsigned tm = split ? 2u + (blockIdx.x & 1u) : 1u;
+        const unsigned tm = split ? 2u + (first & 1u) : 1u;
         for (unsigned i = 32u + t; i < 1024u; i += G::T) {
             const unsigned l0 = 1u << (31u - __clz(i));
             tw2_lds()[i] = tw[l0 * tm + (i - l0)];
@@ -551,27 +589,57 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
     // inverse: the first twiddle group of the first round stays in registers (every polynomial of this workgroup belongs to
     // the same half when the transform is split: the grid is even whenever a workgroup sees more than one polynomial)
     [[maybe_unused]] uint2 W0[GROUP32];
-    if constexpr (!FWD) load_tw32<LOGN, 0, 0, false, 0>(W0, tw, twr, split ? 2u + (blockIdx.x & 1u) : 1u, t);
-    issue_loads(blockIdx.x, true);
+    if constexpr (!FWD) load_tw32<LOGN, 0, 0, false, 0>(W0, tw, twr, split ? 2u + (first & 1u) : 1u, t);
+    issue_loads(first, true);
+    issue_loads_v(first, true);
     static_for<32>([&](auto rc) { v[decltype(rc)::value] = 0; });
     issue_stores(make_rsrc(a, 0u));                       // (zero-length descriptor: dropped; see above)
-    for (unsigned y = blockIdx.x; y < num; y += gridDim.x) {
+    [[maybe_unused]] unsigned it = 0;
+    for (unsigned y = first; y < num; y += stride) {
         const BufRsrc prs = make_rsrc(a + (size_t)y * n, n * 4u);
         const unsigned h = split ? (y & 1u) : 0u, tmul = split ? 2u + h : 1u;
-        const bool more = y + gridDim.x < num;
+        const bool more = y + stride < num;
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = nx[decltype(rc)::value]; });
+        if constexpr (PAIR) {
+            // the stage that couples the halves: U + V w' in [0, 3q) (round 1 takes [0, 4q)); -w = q - w has the companion ~wp
+            // (floor((q - w) 2^32 / q) = 2^32 - 1 - floor(w 2^32 / q): w 2^32 is no multiple of the prime q)
+            const uint2 w1 = tw[1];
+            const u32 cw = h ? q - w1.x : w1.x, cwp = h ? ~w1.y : w1.y;
+            static_for<32>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                v[r] += shoup32(nv[r], cw, cwp, q);
+            });
+        }
         // the prefetch of the next polynomial (unconditional: one instruction stream; past the end it loads nothing) goes in
         // front of the round with scalar twiddle loads: the forward's first, the inverse's last
-        auto prefetch = [&]() { issue_loads(more ? y + gridDim.x : y, more); };
+        auto prefetch = [&]() { issue_loads(more ? y + stride : y, more); };
         if constexpr (FWD) {
             prefetch();
-            fwd_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img);
+            fwd_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img, [&]() {
+                if constexpr (PAIR) {                    // every wave holds its share of the input: the partner may store
+                    unsigned* const mf = flag_at(h);
+                    if (t == 0) __hip_atomic_store(mf, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            });
             static_for<32>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 u32 x = min_u32(v[r], v[r] - 2 * q);
                 v[r] = min_u32(x, x - q);
             });
             __syncthreads();                             // the last exchange has been read by every wave: the image is free
+            if constexpr (PAIR) {
+                // V of the next polynomial in front of the stores (results return in order: behind them it would wait for their
+                // drain), then: has the partner read the input under this result?  (long since, normally; a partner that never
+                // shows up -- tens of seconds -- means the grid is not resident as a whole: abort loudly rather than hang)
+                issue_loads_v(more ? y + stride : y, more);
+                unsigned spin = 0;
+                unsigned* const pf = flag_at(1u - h);
+                while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spin == (1u << 25)) __builtin_trap();
+                }
+                it++;
+            }
 #if !defined(NTT30_NOMEM) && !defined(NTT30_NOSTORE)
             issue_stores(prs);
 #else
@@ -597,6 +665,11 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
 #endif
         }
     }
+    if constexpr (PAIR) {
+        __syncthreads();                                  // every wave has polled for the last time:
+        unsigned* const pf = flag_at(1u - (first & 1u));
+        if (t == 0) __hip_atomic_store(pf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero between launches
+    }
 }
 
 // ---- scratch per (device, stream) -----------------------------------------------------------------------------------
@@ -615,7 +688,7 @@ Scratch30* scratch_for(hipStream_t s)
     if (it != g_scratch.end()) return it->second;
     Scratch30* p = nullptr;
     if (hipMalloc((void**)&p, sizeof(Scratch30)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 64) != hipSuccess) {
+    if (hipMemset(p, 0, offsetof(Scratch30, tw)) != hipSuccess) {
         (void)hipFree(p);
         return nullptr;
     }
@@ -636,8 +709,18 @@ void launch_native(u32* d_a, const Scratch30* sc, u32 q, unsigned num, unsigned 
     const unsigned lds = pad32(1u << LOGN) * 4u, per_cu_lds = 163840u / lds, per_cu_waves = 16u / (Geo<LOGN>::T / 64u);   // 4 waves/SIMD at 128 VGPRs
     unsigned per_cu = per_cu_lds < per_cu_waves ? per_cu_lds : per_cu_waves;
     if (per_cu < 1) per_cu = 1;
-    const unsigned cap = 256u * per_cu;
-    k_ntt30x<LOGN, FWD><<<num < cap ? num : cap, Geo<LOGN>::T, 0, s>>>(d_a, sc, q, num, split);
+    const unsigned cap = current_device_cus() * per_cu;
+    k_ntt30x<LOGN, FWD><<<num < cap ? num : cap, Geo<LOGN>::T, 0, s>>>(d_a, sc, q, num, split, nullptr);
+}
+
+// n = 2^16 forward without the stage launch: two workgroups per polynomial (k_ntt30x PAIR); halves = 2 x polynomials
+bool launch_native_pair(u32* d_a, Scratch30* sc, u32 q, unsigned halves, hipStream_t s)
+{
+    const unsigned cus = current_device_cus() & ~1u;      // one workgroup per CU: the grid is resident as a whole
+    const unsigned grid = halves < cus ? halves : cus;
+    if (grid < 2 || grid > 1024u) return false;
+    k_ntt30x<15, true, true><<<grid, Geo<15>::T, 0, s>>>(d_a, sc, q, halves, 1u, sc->flags);
+    return true;
 }
 
 template <bool FWD>
@@ -696,8 +779,19 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     const unsigned epoch = next_epoch();
     const unsigned split = n == 65536 ? 1u : 0u;
     k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_native, split, FWD ? 1u : 0u, sc, epoch);
-    if (split && FWD) launch_stage<true>(d_a, n, d_tab, 1, num, q, mu, bits, s, nullptr);       // stage 1 couples the two halves
     const unsigned m = split ? n / 2 : n, cnt = split ? 2 * num : num;
+    if constexpr (FWD) {
+        // n = 2^16, from one polynomial per CU pair up and outside stream capture (the flags of the scratch belong to live launches
+        // of this stream only): stage 1 rides in the loads of a pair launch
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        static const bool pair_off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;     // (A/B measurements)
+        if (split && !pair_off && num >= kPair30MinPolys && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
+            launch_native_pair(d_a, sc, q, cnt, s)) {
+            launch_literal<FWD>(d_a, n, d_tab, num, q, mu, bits, s, sc->guard, false);          // fallback leg: every stage
+            return hipGetLastError();
+        }
+    }
+    if (split && FWD) launch_stage<true>(d_a, n, d_tab, 1, num, q, mu, bits, s, nullptr);       // stage 1 couples the two halves
     switch (m) {
     case 2048: launch_native<11, FWD>(d_a, sc, q, cnt, split, s); break;
     case 4096: launch_native<12, FWD>(d_a, sc, q, cnt, split, s); break;

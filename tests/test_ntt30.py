@@ -143,3 +143,71 @@ def test_gpu_30bit_persistent_loop_matches_oracle(native, oracle, gpu, n, num):
     native.inverse30(d_a, n, q, prm.mu, bits, d_psiinv, num)
     torch.cuda.synchronize()
     assert np.array_equal(host32(d_a), a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num", [63, 64, 100, 129, 257])
+def test_gpu_30bit_n65536_pair_launch_matches_oracle(native, oracle, gpu, num):
+    """n = 65536 forward (old/ntt_30bit.cuh:271-283) from 64 polynomials up: no stage launch, two cooperating workgroups per
+    polynomial that read both halves and keep one half of the first stage's output each (k_ntt30x PAIR, one "have read it"
+    flag each way before the in-place stores).  Either side of the switch, odd and even grids (partners on different / the
+    same XCD), workgroups with a second polynomial; adversarial words; then a table with an entry >= q behind the same
+    launch (the native kernel steps aside on the device, the literal leg runs every stage), two streams at once, and a
+    captured graph (capturing streams keep the stage launch)."""
+    import torch
+    n = 65536
+    q, psi, _, _, bits = PARAMS30[n]
+    prm = oracle.Params30(n, q, psi)
+    rng = np.random.default_rng(num)
+    a = rng.integers(0, q, size=(num, n), dtype=np.uint32)
+    a[0, :4] = [0, q - 1, 1, q - 1]
+    a[0, n // 2 - 2: n // 2 + 2] = q - 1
+    a[num - 1, :] = q - 1
+    dev32 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int32)).to(gpu)
+    host32 = lambda t: t.cpu().numpy().view(np.uint32)
+    d_psi, d_psiinv = dev32(prm.psi_tab), dev32(prm.psiinv_tab)
+    A = oracle.forward30(a, prm)
+    d_a = dev32(a)
+    native.forward30(d_a, n, q, prm.mu, bits, d_psi, num)
+    assert np.array_equal(host32(d_a), A)
+    native.inverse30(d_a, n, q, prm.mu, bits, d_psiinv, num)
+    assert np.array_equal(host32(d_a), a)
+    if num not in (64, 129):
+        return
+    # a table entry q + w (same residue, not canonical): the literal arithmetic on exactly that table, then the clean table again
+    prm3 = oracle.Params30(n, q, psi)
+    prm3.psi_tab = prm3.psi_tab.copy()
+    prm3.psi_tab[1] += q                             # (the entry of the stage that couples the halves)
+    small = a[:num]
+    d_b = dev32(small)
+    native.forward30(d_b, n, q, prm3.mu, bits, dev32(prm3.psi_tab), num)
+    assert np.array_equal(host32(d_b), oracle.forward30(small, prm3))
+    d_b = dev32(a)
+    native.forward30(d_b, n, q, prm.mu, bits, d_psi, num)
+    assert np.array_equal(host32(d_b), A)
+    # two streams, nobody waits (each stream has its own scratch table and flags)
+    d_c, d_d = dev32(a), dev32(a)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(2):
+        native.forward30(d_c, n, q, prm.mu, bits, d_psi, num, stream=s1)
+        native.forward30(d_d, n, q, prm.mu, bits, d_psi, num, stream=s2)
+        native.inverse30(d_c, n, q, prm.mu, bits, d_psiinv, num, stream=s1)
+        native.inverse30(d_d, n, q, prm.mu, bits, d_psiinv, num, stream=s2)
+    native.forward30(d_c, n, q, prm.mu, bits, d_psi, num, stream=s1)
+    native.forward30(d_d, n, q, prm.mu, bits, d_psi, num, stream=s2)
+    torch.cuda.synchronize()
+    assert np.array_equal(host32(d_c), A) and np.array_equal(host32(d_d), A)
+    # captured (the first call on the capture stream happens outside the capture: it allocates the stream's scratch table)
+    cs = torch.cuda.Stream()
+    d_e = dev32(a)
+    native.forward30(d_e, n, q, prm.mu, bits, d_psi, num, stream=cs)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cs):
+        native.inverse30(d_e, n, q, prm.mu, bits, d_psiinv, num)
+        native.forward30(d_e, n, q, prm.mu, bits, d_psi, num)
+    for _ in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(host32(d_e), A)
