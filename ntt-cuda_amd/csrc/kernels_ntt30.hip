@@ -522,7 +522,6 @@ template <int LOGN, bool FWD, bool PAIR = false>
 __global__ void __launch_bounds__(Geo<LOGN>::T, 4)       // 128 VGPRs: four waves per SIMD, i.e. as many workgroups per CU as the LDS image admits
 k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned num, unsigned split, unsigned* __restrict__ flags)
 {
-    static_assert(!PAIR || FWD, "the pair form exists for the forward transform");
     if (sc->guard[0] == sc->guard[1]) return;            // a table entry >= q: the literal leg transforms the data
     using G = Geo<LOGN>;
     constexpr unsigned n = G::N;
@@ -551,7 +550,7 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
     u32 v[32], nx[32];
     [[maybe_unused]] u32 nv[PAIR ? 32 : 1];
     auto issue_loads = [&](unsigned y, bool real) {
-        const BufRsrc rs = make_rsrc(a + (size_t)(PAIR ? y & ~1u : y) * n, real ? n * 4u : 0u);      // (PAIR: the lower half U)
+        const BufRsrc rs = make_rsrc(a + (size_t)(PAIR && FWD ? y & ~1u : y) * n, real ? n * 4u : 0u);      // (PAIR forward: the lower half U)
 #if defined(NTT30_NOMEM) || defined(NTT30_NOLOAD)         // timing experiment: no polynomial traffic
         static_for<32>([&](auto rc) { nx[decltype(rc)::value] = (t + decltype(rc)::value + y) & 0xffffu; });
         return;
@@ -561,8 +560,8 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
         else
             issue_row_loads32(nx, rs, t);
     };
-    auto issue_loads_v = [&](unsigned y, bool real) {     // PAIR: the upper half V of the same full-size polynomial
-        if constexpr (PAIR) {
+    auto issue_loads_v = [&](unsigned y, bool real) {     // PAIR forward: the upper half V of the same full-size polynomial
+        if constexpr (PAIR && FWD) {
             const BufRsrc rs = make_rsrc(a + (size_t)(y | 1u) * n, real ? n * 4u : 0u);
             static_for<32>([&](auto rc) { nv[decltype(rc)::value] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 0); });
         }
@@ -654,6 +653,41 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
             rows_to_layout0_32(v, img, t);
             inv_rounds32<LOGN, 0>(v, tw, twr, tmul, t, q, img, sc, h, prefetch, &W0);
             static_for<32>([&](auto rc) { v[decltype(rc)::value] = min_u32(v[decltype(rc)::value], v[decltype(rc)::value] - q); });
+            if constexpr (PAIR) {
+                // PAIR inverse: no stage launch behind.  The half-size results X (lower) and Y (upper) carry n^-1 already (the host
+                // passes (2m)^-1); the last GS stage is X + Y below and (X - Y) psi^-bitrev(1) above.  The upper workgroup writes Y
+                // through to memory, drains, and counts it in flags[2 pair + 1]; the lower one waits for that count, reads Y back
+                // (system-scope loads: the two may sit on different XCDs) and stores both halves of the result -- the upper
+                // workgroup is done with its half by then, so one flag suffices.
+                const BufRsrc urs = make_rsrc(a + (size_t)(y | 1u) * n, n * 4u);
+                if (h == 1) {
+                    static_for<32>([&](auto rc) { __builtin_amdgcn_raw_buffer_store_b32(v[decltype(rc)::value], urs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 17); });
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                      // every wave's words are in memory
+                    unsigned* const mf = flag_at(1u);
+                    if (t == 0) __hip_atomic_store(mf, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    unsigned spin = 0;
+                    unsigned* const pf = flag_at(1u);
+                    while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spin == (1u << 25)) __builtin_trap();      // (the partner never became resident: see the forward form)
+                    }
+                    u32 yy[32];
+                    static_for<32>([&](auto rc) { yy[decltype(rc)::value] = __builtin_amdgcn_raw_buffer_load_b32(urs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 17); });
+                    const uint2 w1 = tw[1];
+                    static_for<32>([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        const u32 X = v[r], Y = yy[r];
+                        const u32 lo = min_u32(X + Y, X + Y - q);
+                        u32 hi = shoup32(X + q - Y, w1.x, w1.y, q);
+                        hi = min_u32(hi, hi - q);
+                        __builtin_amdgcn_raw_buffer_store_b32(lo, prs, t * 4u, ((unsigned)r << G::B0) * 4u, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(hi, urs, t * 4u, ((unsigned)r << G::B0) * 4u, 0);
+                    });
+                }
+                it++;
+            } else {
 #if !defined(NTT30_NOMEM) && !defined(NTT30_NOSTORE)
             issue_stores(prs);
 #else
@@ -663,12 +697,13 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
                 if (x == 0xdeadbeefu) a[t] = x;
             }
 #endif
+            }
         }
     }
     if constexpr (PAIR) {
         __syncthreads();                                  // every wave has polled for the last time:
-        unsigned* const pf = flag_at(1u - (first & 1u));
-        if (t == 0) __hip_atomic_store(pf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero between launches
+        unsigned* const pf = flag_at(FWD ? 1u - (first & 1u) : 1u);
+        if (t == 0 && (FWD || (first & 1u) == 0)) __hip_atomic_store(pf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero between launches
     }
 }
 
@@ -713,14 +748,17 @@ void launch_native(u32* d_a, const Scratch30* sc, u32 q, unsigned num, unsigned 
     k_ntt30x<LOGN, FWD><<<num < cap ? num : cap, Geo<LOGN>::T, 0, s>>>(d_a, sc, q, num, split, nullptr);
 }
 
-// n = 2^16 forward without the stage launch: two workgroups per polynomial (k_ntt30x PAIR); halves = 2 x polynomials
-bool launch_native_pair(u32* d_a, Scratch30* sc, u32 q, unsigned halves, hipStream_t s)
+// n = 2^16 without the stage launch: two workgroups per polynomial (k_ntt30x PAIR); halves = 2 x polynomials
+inline unsigned pair_grid(unsigned halves)
 {
     const unsigned cus = current_device_cus() & ~1u;      // one workgroup per CU: the grid is resident as a whole
     const unsigned grid = halves < cus ? halves : cus;
-    if (grid < 2 || grid > 1024u) return false;
-    k_ntt30x<15, true, true><<<grid, Geo<15>::T, 0, s>>>(d_a, sc, q, halves, 1u, sc->flags);
-    return true;
+    return grid < 2 || grid > 1024u ? 0u : grid;
+}
+template <bool FWD>
+void launch_native_pair(u32* d_a, Scratch30* sc, u32 q, unsigned halves, unsigned grid, hipStream_t s)
+{
+    k_ntt30x<15, FWD, true><<<grid, Geo<15>::T, 0, s>>>(d_a, sc, q, halves, 1u, sc->flags);
 }
 
 template <bool FWD>
@@ -778,18 +816,22 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     std::lock_guard<std::mutex> launch_lock(g_launch30_mutex);
     const unsigned epoch = next_epoch();
     const unsigned split = n == 65536 ? 1u : 0u;
-    k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_native, split, FWD ? 1u : 0u, sc, epoch);
     const unsigned m = split ? n / 2 : n, cnt = split ? 2 * num : num;
-    if constexpr (FWD) {
-        // n = 2^16, from one polynomial per CU pair up and outside stream capture (the flags of the scratch belong to live launches
-        // of this stream only): stage 1 rides in the loads of a pair launch
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    // n = 2^16, from one polynomial per CU pair up and outside stream capture (the flags of the scratch belong to live launches of
+    // this stream only): the stage that couples the halves rides in a pair launch -- in its loads (forward) / behind its last
+    // round (inverse, which then scales by n^-1 = m^-1 / 2 itself)
+    unsigned pgrid = 0;
+    if (split && num >= kPair30MinPolys) {
         static const bool pair_off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;     // (A/B measurements)
-        if (split && !pair_off && num >= kPair30MinPolys && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone &&
-            launch_native_pair(d_a, sc, q, cnt, s)) {
-            launch_literal<FWD>(d_a, n, d_tab, num, q, mu, bits, s, sc->guard, false);          // fallback leg: every stage
-            return hipGetLastError();
-        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (!pair_off && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) pgrid = pair_grid(cnt);
+    }
+    const unsigned ninv_k = (pgrid && !FWD) ? (unsigned)(((u64)ninv_native * ((q + 1) / 2)) % q) : ninv_native;
+    k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_k, split, FWD ? 1u : 0u, sc, epoch);
+    if (pgrid) {
+        launch_native_pair<FWD>(d_a, sc, q, cnt, pgrid, s);
+        launch_literal<FWD>(d_a, n, d_tab, num, q, mu, bits, s, sc->guard, false);              // fallback leg: every stage
+        return hipGetLastError();
     }
     if (split && FWD) launch_stage<true>(d_a, n, d_tab, 1, num, q, mu, bits, s, nullptr);       // stage 1 couples the two halves
     switch (m) {

@@ -148,9 +148,10 @@ def test_gpu_30bit_persistent_loop_matches_oracle(native, oracle, gpu, n, num):
 @pytest.mark.gpu
 @pytest.mark.parametrize("num", [63, 64, 100, 129, 257])
 def test_gpu_30bit_n65536_pair_launch_matches_oracle(native, oracle, gpu, num):
-    """n = 65536 forward (old/ntt_30bit.cuh:271-283) from 64 polynomials up: no stage launch, two cooperating workgroups per
-    polynomial that read both halves and keep one half of the first stage's output each (k_ntt30x PAIR, one "have read it"
-    flag each way before the in-place stores).  Either side of the switch, odd and even grids (partners on different / the
+    """n = 65536 (old/ntt_30bit.cuh:271-283,323-331) from 64 polynomials up: no stage launch, two cooperating workgroups per
+    polynomial (k_ntt30x PAIR).  Forward: both read both halves and keep one half of the first stage's output each, one "have
+    read it" flag each way before the in-place stores.  Inverse: the upper workgroup writes its half-size result through and
+    counts it, the lower one reads it back and stores both halves of the last stage's output.  Either side of the switch, odd and even grids (partners on different / the
     same XCD), workgroups with a second polynomial; adversarial words; then a table with an entry >= q behind the same
     launch (the native kernel steps aside on the device, the literal leg runs every stage), two streams at once, and a
     captured graph (capturing streams keep the stage launch)."""
@@ -185,6 +186,17 @@ def test_gpu_30bit_n65536_pair_launch_matches_oracle(native, oracle, gpu, num):
     d_b = dev32(a)
     native.forward30(d_b, n, q, prm.mu, bits, d_psi, num)
     assert np.array_equal(host32(d_b), A)
+    # the same for the inverse (pair launch: the upper workgroup hands its half-size result to the lower one, which applies the
+    # last stage): entry 1 of the inverse table not canonical -> literal leg, every stage; then the clean table again
+    prm4 = oracle.Params30(n, q, psi)
+    prm4.psiinv_tab = prm4.psiinv_tab.copy()
+    prm4.psiinv_tab[1] += q
+    d_b = dev32(A)
+    native.inverse30(d_b, n, q, prm4.mu, bits, dev32(prm4.psiinv_tab), num)
+    assert np.array_equal(host32(d_b), oracle.inverse30(A, prm4))
+    d_b = dev32(A)
+    native.inverse30(d_b, n, q, prm.mu, bits, d_psiinv, num)
+    assert np.array_equal(host32(d_b), a)
     # two streams, nobody waits (each stream has its own scratch table and flags)
     d_c, d_d = dev32(a), dev32(a)
     torch.cuda.synchronize()
