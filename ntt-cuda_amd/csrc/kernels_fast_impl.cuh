@@ -466,6 +466,18 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
         asm volatile("" : "+s"(f));
         return flags + f;
     };
+    unsigned it = 0;
+    // the partner has read the input under this result?  (long since, normally.  A partner that never shows up -- tens of seconds --
+    // means the grid is not resident as a whole, which the launch rules exclude: abort the kernel, loudly, rather than hang or
+    // store over words the partner still needs)
+    auto wait_for_partner = [&]() {
+        unsigned spin = 0;
+        unsigned* const partner_flag = flag_at(1u - role);
+        while (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spin == (1u << 25)) __builtin_trap();
+        }
+    };
     unsigned y = pair;
     if (y >= num) return;
     {
@@ -481,7 +493,6 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
     };
     unsigned ymod = __builtin_amdgcn_readfirstlane(pair % division), ystep = __builtin_amdgcn_readfirstlane(npairs % division);
     asm volatile("" : "+s"(ymod), "+s"(ystep));
-    unsigned it = 0;
     // (the loop is entered one pass early, with nothing to transform yet: ONE request site -- two of them, in front of the loop and
     // at its tail, meet at the back edge with different register assignments, and the fix-up parks loaded words in scratch behind
     // a full wait)
@@ -527,17 +538,7 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
         ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
-        // the partner has read the input under this result?  (long since, normally.  A partner that never shows up -- seconds --
-        // means the grid is not resident as a whole, which the launch rules exclude: abort the kernel, loudly, rather than hang
-        // or store over words the partner still needs)
-        {
-            unsigned spin = 0;
-            unsigned* const partner_flag = flag_at(1u - role);
-            while (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spin == (1u << 25)) __builtin_trap();
-            }
-        }
+        wait_for_partner();
         wave_store_rows(v, slice, make_rsrc(a + (size_t)(2 * y + role) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
         it++;
         ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep);

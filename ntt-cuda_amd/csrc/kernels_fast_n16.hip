@@ -61,8 +61,9 @@ hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* 
     dispatch_class(hl, [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
-        // (the 61/62-bit classes -- exact quotients, a reduction in every stage -- do not fit 128 VGPRs in this form: they keep the
-        // single-workgroup launch, fast_forward_split16 asks fast_fwd_pair_ok_16 first)
+        // (the 61/62-bit classes -- exact quotients, a reduction in every stage -- fit 128 VGPRs in this form only with spills and
+        // then run slower than the single-workgroup launch, 0.267 against 0.226 ms per 512 polynomials: they keep that one,
+        // fast_forward_split16 asks fast_fwd_pair_ok_16 first)
         if constexpr (H >= 4) k_forward15_pair<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num, d_flags);
         else launched = false;
     });
