@@ -201,6 +201,49 @@ def test_n65536_fused_coupling_launches_match_oracle(native, oracle, gpu, form, 
     ctx.close()
 
 
+def _n16_child(form, num, env_extra):
+    """forward / inverse / product digests of an n = 2^16 batch in a child process (the dispatch switches are read once per process)"""
+    qs = N16_FORMS[form]
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, numpy as np
+import ntt_cuda_amd as ntt
+n, num, qs = 65536, %d, %r
+psis = [next(x for x in (pow(g, (q - 1) // (2 * n), q) for g in range(2, 1000)) if pow(x, n, q) == q - 1) for q in qs]
+ctx = ntt.NTTContext(n, qs, psis)
+a = torch.empty((num, n), dtype=torch.int64, device="cuda:0"); b = torch.empty_like(a)
+ctx.synth_splitmix(a, num, 5); ctx.synth_splitmix(b, num, 77777)
+a0 = a.clone()
+ctx.forward_batch(a, num); ctx.forward_batch(b, num)
+h = [hashlib.sha256(ntt.to_host(a).tobytes()).hexdigest()]
+ctx.inverse_batch(a, num)
+assert torch.equal(a, a0)
+ctx.inverse_batch(b, num)
+h.append(hashlib.sha256(ntt.to_host(b).tobytes()).hexdigest())
+ctx.polymul_batch(a, b, num)
+h.append(hashlib.sha256(ntt.to_host(a).tobytes()).hexdigest())
+print(" ".join(h))
+''' % (os.path.join(ROOT, "ntt-cuda_amd"), os.path.join(ROOT, "tests"), num, list(qs))
+    env = dict(os.environ)
+    for k in ("MI355NTT_LATENCY_PATH_MAX", "MI355NTT_NO_PAIR16"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout.strip().splitlines()[-1]
+
+
+@pytest.mark.parametrize("form", ["hl4-near", "hl6-general", "hl4-general"])
+def test_n65536_every_route_gives_the_same_words(native, gpu, form):
+    """n = 2^16, 200 polynomials of the classes that take the pair launch by default: the pair launch, the single-workgroup
+    launches it falls back to (MI355NTT_NO_PAIR16: what capturing streams and second streams get) and the stage launch around
+    the small-batch kernels (MI355NTT_LATENCY_PATH_MAX: large) must agree on forward, inverse and product -- the default route is
+    checked against the oracle in the test above."""
+    outs = [_n16_child(form, 200, e) for e in ({}, {"MI355NTT_NO_PAIR16": "1"}, {"MI355NTT_LATENCY_PATH_MAX": "100000"})]
+    assert outs[0] == outs[1] == outs[2], outs
+
+
 def test_n65536_pair_launches_share_the_device_between_streams_and_graphs(native, oracle, gpu):
     """The n = 2^16 forward transform of a large batch runs two workgroups per polynomial that hand each other a flag
     (k_forward15_pair); the device's flag buffer belongs to one stream at a time, a second stream with work in flight and a
