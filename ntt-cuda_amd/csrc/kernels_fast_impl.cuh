@@ -38,6 +38,12 @@ __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restri
     });
 }
 
+// cache policy of the coalesced 8-byte RESULT stores of k_inverse<LOGN> / k_polymul<LOGN> (n = 2^11 .. 2^14): 17 = written through,
+// as on n = 2^15 (MI355NTT_INV15_AUX_ST below).  A/B on one box, two rounds each: n = 2^13 inverse 0.171 -> 0.168 ms, n = 2^14 fused
+// 0.334 -> 0.329 ms per 256 MiB, every other size and kernel within +-0.5 %: small, never worse.
+#ifndef MI355NTT_INV_AUX_ST
+#define MI355NTT_INV_AUX_ST 17
+#endif
 template <int LOGN, int AUX = MI355NTT_STREAM_AUX_ST>
 __device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restrict__ poly, unsigned t)
 {
@@ -152,7 +158,7 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         inverse_core<LOGN, HL, NEAR>(v, twp, tid, p, lds, primes[idx].twn);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP(8);
-        store_coalesced<LOGN>(v, poly, tid());
+        store_coalesced<LOGN, MI355NTT_INV_AUX_ST>(v, poly, tid());
 #if MI355NTT_SMALL_ROW_STAGING
         __syncthreads();        // every wave has read the last exchange: the image is free for the row staging
         if (y + gridDim.x < num)
@@ -950,7 +956,7 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     inverse_core<LOGN, HL, NEAR, FusedMul<HL, NEAR>::LAZY>(v, twi + (size_t)idx * G::N, tid, p, lds, primes[idx].twn);
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL, NEAR>(v[r], p);
-    store_coalesced<LOGN>(v, poly, tid());
+    store_coalesced<LOGN, MI355NTT_INV_AUX_ST>(v, poly, tid());
 }
 
 // Workgroups that can be resident at once: 256 CUs x (what 128 VGPRs/thread, the LDS image and 32 waves/CU admit).

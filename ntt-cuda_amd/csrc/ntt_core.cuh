@@ -32,7 +32,7 @@
     defined(MI355NTT_PSPLIT_R1) || defined(MI355NTT_PSPLIT_R2) || defined(MI355NTT_PSPLIT_R3) || defined(MI355NTT_PSPLIT_I1) || \
     defined(MI355NTT_PSPLIT_I2) || defined(MI355NTT_PSPLIT_I3) || defined(MI355NTT_STAGGER_FWD) || defined(MI355NTT_STAGGER_INV) || \
     defined(MI355NTT_STAGGER_FWD_MULTI) || defined(MI355NTT_STAGGER_INV_MULTI) || defined(MI355NTT_STAGGER_MUL) || \
-    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_DESCENDING)
+    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_AUX_ST) || defined(MI355NTT_INV_DESCENDING)
 #error "MI355NTT_* experiment switches are for measurement builds only: add -DMI355NTT_LAB (tools/build_kbench.sh); a library build must not define them"
 #endif
 #endif
