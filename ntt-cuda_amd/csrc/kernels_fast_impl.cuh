@@ -442,8 +442,10 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
 // through the L2) and is written once: 1 x / 1 x instead of the 1.5 x / 1.5 x of the single-workgroup form (k_forward15 SPLIT).
 // The transform is in place, so a workgroup must not store its half of the result before the partner has READ the input
 // underneath: one flag per workgroup, `flags[2 pair + role]` = number of polynomials this workgroup has read completely (written
-// after the barrier behind round 1, polled before the row store ~25 us later; agent scope, relaxed: the protected accesses are
-// loads that have returned before the flag is written and stores issued after it is seen).  The flags are zero between launches
+// after the barrier behind round 1, polled before the row store ~25 us later; agent scope, relaxed: what the flag protects is a
+// write-after-read hazard -- the partner's loads have returned (their values are consumed in front of the barrier) before it
+// writes the flag, and this workgroup's stores are issued only after it has seen the flag; no data travels with the flag, so
+// there is nothing to release or acquire).  The flags are zero between launches
 // (each workgroup clears the one it polls on exit); the buffer belongs to one stream at a time (kernels_fast.hip).  Grid: an even
 // number of workgroups, all resident (one per CU).
 template <int HL, bool NEAR>

@@ -658,7 +658,10 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
                 // passes (2m)^-1); the last GS stage is X + Y below and (X - Y) psi^-bitrev(1) above.  The upper workgroup writes Y
                 // through to memory, drains, and counts it in flags[2 pair + 1]; the lower one waits for that count, reads Y back
                 // (system-scope loads: the two may sit on different XCDs) and stores both halves of the result -- the upper
-                // workgroup is done with its half by then, so one flag suffices.
+                // workgroup is done with its half by then, so one flag suffices.  The hand-off is the guide's write-through form
+                // (MI355X_MICROARCH.md, inter-workgroup visibility): every handed-off byte stored sc0 sc1, every storing wave drained
+                // (vmcnt(0)) and the workgroup's barrier passed before the count is published, every load of those bytes sc0 sc1 --
+                // no L2 write-back / L1 invalidate per polynomial.
                 const BufRsrc urs = make_rsrc(a + (size_t)(y | 1u) * n, n * 4u);
                 if (h == 1) {
                     static_for<32>([&](auto rc) { __builtin_amdgcn_raw_buffer_store_b32(v[decltype(rc)::value], urs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 17); });
