@@ -214,7 +214,10 @@ __device__ __forceinline__ u32 shoup32(u32 y, u32 w, u32 wp, u32 q) { return y *
 // layouts is conflict-free or 2-way).  Thread part and register part of an index occupy disjoint bit fields, so the slot
 // splits into a per-thread base and a compile-time offset per register.
 constexpr unsigned pad32(unsigned i) { return i + (i >> 5); }
-constexpr unsigned kPair30MinPolys = 64;              // (below: the stage launch + one workgroup per half; tools/bench30.py)
+// n = 2^16: polynomials per call from which the pair launches win over the stage launch + one workgroup per half (tools/crossover30.py,
+// profiles/r03_ntt30_n65536_pair.txt): forward from 32 (63.6 against 68.0 us), inverse -- whose lower workgroup carries the last stage alone --
+// from a few hundred (256: 116.8 = 116.8 us, 512: 169.6 against 176.1 us)
+constexpr unsigned kPair30MinPolysFwd = 32, kPair30MinPolysInv = 384;
 
 template <int BO, int BN>
 __device__ __forceinline__ void exchange32(u32 (&v)[32], u32* img, unsigned t)
@@ -820,11 +823,11 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     const unsigned epoch = next_epoch();
     const unsigned split = n == 65536 ? 1u : 0u;
     const unsigned m = split ? n / 2 : n, cnt = split ? 2 * num : num;
-    // n = 2^16, from one polynomial per CU pair up and outside stream capture (the flags of the scratch belong to live launches of
+    // n = 2^16, large enough calls (kPair30MinPolys*) outside stream capture (the flags of the scratch belong to live launches of
     // this stream only): the stage that couples the halves rides in a pair launch -- in its loads (forward) / behind its last
     // round (inverse, which then scales by n^-1 = m^-1 / 2 itself)
     unsigned pgrid = 0;
-    if (split && num >= kPair30MinPolys) {
+    if (split && num >= (FWD ? kPair30MinPolysFwd : kPair30MinPolysInv)) {
         static const bool pair_off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;     // (A/B measurements)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (!pair_off && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) pgrid = pair_grid(cnt);

@@ -146,10 +146,10 @@ def test_gpu_30bit_persistent_loop_matches_oracle(native, oracle, gpu, n, num):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("num", [63, 64, 100, 129, 257])
+@pytest.mark.parametrize("num", [31, 32, 100, 129, 383, 384, 420])
 def test_gpu_30bit_n65536_pair_launch_matches_oracle(native, oracle, gpu, num):
-    """n = 65536 (old/ntt_30bit.cuh:271-283,323-331) from 64 polynomials up: no stage launch, two cooperating workgroups per
-    polynomial (k_ntt30x PAIR).  Forward: both read both halves and keep one half of the first stage's output each, one "have
+    """n = 65536 (old/ntt_30bit.cuh:271-283,323-331), large calls (forward from 32, inverse from 384 polynomials): no stage launch,
+    two cooperating workgroups per polynomial (k_ntt30x PAIR).  Forward: both read both halves and keep one half of the first stage's output each, one "have
     read it" flag each way before the in-place stores.  Inverse: the upper workgroup writes its half-size result through and
     counts it, the lower one reads it back and stores both halves of the last stage's output.  Either side of the switch, odd and even grids (partners on different / the
     same XCD), workgroups with a second polynomial; adversarial words; then a table with an entry >= q behind the same
@@ -173,7 +173,7 @@ def test_gpu_30bit_n65536_pair_launch_matches_oracle(native, oracle, gpu, num):
     assert np.array_equal(host32(d_a), A)
     native.inverse30(d_a, n, q, prm.mu, bits, d_psiinv, num)
     assert np.array_equal(host32(d_a), a)
-    if num not in (64, 129):
+    if num not in (32, 129, 420):
         return
     # a table entry q + w (same residue, not canonical): the literal arithmetic on exactly that table, then the clean table again
     prm3 = oracle.Params30(n, q, psi)
