@@ -48,8 +48,12 @@ __device__ __forceinline__ bool literal_leg_skips(const unsigned* guard) { retur
 // all stages of CTBasedNTTInner(Single) (old/ntt_30bit.cuh:70-129, 199-227) / GSBasedINTTInner(Single) (:131-196, 229-267)
 template <int LOGN, bool FWD>
 __global__ void __launch_bounds__(1024)
-k_ntt30(u32* __restrict__ a, const u32* __restrict__ tab, u32 q, u32 mu, int qbit, unsigned num, const unsigned* __restrict__ guard)
+k_ntt30(u32* __restrict__ a, const u32* __restrict__ tab, u32 q, u32 mu, int qbit, unsigned num, const unsigned* __restrict__ guard,
+        unsigned split)
 {
+    // split: the polynomials are the halves of 2^(LOGN+1)-word polynomials whose first (forward) / last (inverse) stage runs as a
+    // stage launch: stage L of half h is the sub-block [L (2 + h), L (2 + h) + L) of the caller's stage block 2 L -- the same
+    // butterflies on the same words as that stage of the full-size transform, so the words are the reference's
     if (literal_leg_skips(guard)) return;
     constexpr unsigned n = 1u << LOGN, T = n / 2 < 1024 ? n / 2 : 1024, PER = n / 2 / T;
     __shared__ u32 s[n];
@@ -57,6 +61,7 @@ k_ntt30(u32* __restrict__ a, const u32* __restrict__ tab, u32 q, u32 mu, int qbi
     const u32 q2 = (q + 1) >> 1;
     for (unsigned y = blockIdx.x; y < num; y += gridDim.x) {
         u32* poly = a + (size_t)y * n;
+        const unsigned tm = split ? 2u + (y & 1u) : 1u;
         for (unsigned i = t; i < n; i += T) s[i] = poly[i];
         __syncthreads();
         if constexpr (FWD) {
@@ -66,7 +71,7 @@ k_ntt30(u32* __restrict__ a, const u32* __restrict__ tab, u32 q, u32 mu, int qbi
                     const unsigned g = t + it * T;
                     const unsigned psi_step = g / step;
                     const unsigned j = psi_step * step * 2 + g % step;
-                    const u32 psi = tab[length + psi_step];
+                    const u32 psi = tab[length * tm + psi_step];
                     u32 U = s[j];
                     const u32 V = barrett30((u64)s[j + step] * psi, q, mu, qbit);
                     u32 r = U + V;
@@ -84,7 +89,7 @@ k_ntt30(u32* __restrict__ a, const u32* __restrict__ tab, u32 q, u32 mu, int qbi
                     const unsigned g = t + it * T;
                     const unsigned psi_step = g / step;
                     const unsigned j = psi_step * step * 2 + g % step;
-                    const u32 psiinv = tab[length + psi_step];
+                    const u32 psiinv = tab[length * tm + psi_step];
                     u32 U = s[j];
                     const u32 V = s[j + step];
                     u32 r = U + V;
@@ -773,11 +778,11 @@ void launch_literal_lds(unsigned* d_a, unsigned n, const unsigned* d_tab, unsign
 {
     const unsigned g = num < 512u ? num : 512u;
     switch (n) {
-    case 2048: k_ntt30<11, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
-    case 4096: k_ntt30<12, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
-    case 8192: k_ntt30<13, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
-    case 16384: k_ntt30<14, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
-    default: k_ntt30<15, FWD><<<g < 256u ? g : 256u, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard); break;
+    case 2048: k_ntt30<11, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard, 0u); break;
+    case 4096: k_ntt30<12, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard, 0u); break;
+    case 8192: k_ntt30<13, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard, 0u); break;
+    case 16384: k_ntt30<14, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard, 0u); break;
+    default: k_ntt30<15, FWD><<<g < 256u ? g : 256u, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard, 0u); break;
     }
 }
 
@@ -799,11 +804,15 @@ void launch_literal(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned n
         launch_literal_lds<FWD>(d_a, n, d_tab, num, q, mu, bits, s, guard);
         return;
     }
+    // n = 2^16: the stage that couples the halves in memory, every other stage out of LDS on the two halves (three launches instead
+    // of sixteen: as the guarded fallback leg they are enqueued with every call)
+    const unsigned halves = 2 * num, g = halves < 256u ? halves : 256u;
     if (FWD) {
-        for (unsigned length = skip_split_stage ? 2 : 1; length < n; length *= 2) launch_stage<true>(d_a, n, d_tab, length, num, q, mu, bits, s, guard);
+        if (!skip_split_stage) launch_stage<true>(d_a, n, d_tab, 1, num, q, mu, bits, s, guard);
+        k_ntt30<15, true><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, halves, guard, 1u);
     } else {
-        for (unsigned length = n / 2; length >= (skip_split_stage ? 2u : 1u); length /= 2)
-            launch_stage<false>(d_a, n, d_tab, length, num, q, mu, bits, s, guard);
+        k_ntt30<15, false><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, halves, guard, 1u);
+        if (!skip_split_stage) launch_stage<false>(d_a, n, d_tab, 1, num, q, mu, bits, s, guard);
     }
 }
 
