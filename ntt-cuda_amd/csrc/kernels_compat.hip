@@ -216,16 +216,20 @@ void launch_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsi
     const unsigned bpp = (n / 2 + kBlock - 1) / kBlock, sh = log2u(bpp);
     const unsigned long long total = (unsigned long long)num << sh;
     const unsigned blocks = total > 0xffffffffull ? 0xffffffffu : (unsigned)total;
-    const unsigned grid = blocks < 8192u ? blocks : 8192u;          // capped: a guarded launch that has nothing to do must cost ~nothing
+    // capped: a guarded launch that has nothing to do must cost ~nothing (its price is the dispatch of its workgroups: 1024 of them
+    // when the launch is a fallback leg that normally returns at once, 8192 when it is the transform)
+    const unsigned cap = guard ? 1024u : 8192u;
+    const unsigned grid = blocks < cap ? blocks : cap;
     if (FWD) ct_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, sh, blocks, m, guard);
     else gs_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, sh, blocks, m, guard);
 }
 
 // workgroups of the LDS kernel: as many as can be resident (160 KiB of LDS per CU), each strides over the slices
-unsigned lds_grid(unsigned slices, int logs)
+unsigned lds_grid(unsigned slices, int logs, bool guarded = false)
 {
     const unsigned per_cu = 163840u / (8u << logs) ? 163840u / (8u << logs) : 1u;
-    const unsigned cap = current_device_cus() * (per_cu > 2 ? 2 : per_cu);          // 1024-thread workgroups: at most two per CU
+    // 1024-thread workgroups: at most two per CU (one for a guarded fallback leg: it normally returns at once, see launch_stage)
+    const unsigned cap = current_device_cus() * (guarded ? 1u : per_cu > 2 ? 2 : per_cu);
     return slices < cap ? slices : cap;
 }
 
@@ -235,16 +239,16 @@ unsigned launch_literal_lds(u64* d_a, unsigned n, const u64* d_tabs, unsigned nu
                             const unsigned* guard)
 {
     switch (n) {
-    case 2048: literal_lds_kernel<11, FWD><<<lds_grid(num, 11), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
-    case 4096: literal_lds_kernel<12, FWD><<<lds_grid(num, 12), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
-    case 8192: literal_lds_kernel<13, FWD><<<lds_grid(num, 13), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
-    case 16384: literal_lds_kernel<14, FWD><<<lds_grid(num, 14), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    case 2048: literal_lds_kernel<11, FWD><<<lds_grid(num, 11, guard != nullptr), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    case 4096: literal_lds_kernel<12, FWD><<<lds_grid(num, 12, guard != nullptr), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    case 8192: literal_lds_kernel<13, FWD><<<lds_grid(num, 13, guard != nullptr), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
+    case 16384: literal_lds_kernel<14, FWD><<<lds_grid(num, 14, guard != nullptr), 1024, 0, s>>>(d_a, d_tabs, n, division, num, m, guard); return 1;
     default: break;
     }
     if (n >= 32768 && n <= (1u << 20) && (n & (n - 1)) == 0) {
         const unsigned spp = n >> 14;
         if ((unsigned long long)num * spp > 0x7fffffffull) return 0;
-        literal_lds_kernel<14, FWD><<<lds_grid(num * spp, 14), 1024, 0, s>>>(d_a, d_tabs, n, division, num * spp, m, guard);
+        literal_lds_kernel<14, FWD><<<lds_grid(num * spp, 14, guard != nullptr), 1024, 0, s>>>(d_a, d_tabs, n, division, num * spp, m, guard);
         return spp;
     }
     return 0;
