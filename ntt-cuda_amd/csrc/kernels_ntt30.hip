@@ -776,7 +776,7 @@ template <bool FWD>
 void launch_literal_lds(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, hipStream_t s,
                         const unsigned* guard)
 {
-    const unsigned g = num < 512u ? num : 512u;
+    const unsigned gmax = guard ? 256u : 512u, g = num < gmax ? num : gmax;      // (guarded: see launch_stage)
     switch (n) {
     case 2048: k_ntt30<11, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard, 0u); break;
     case 4096: k_ntt30<12, FWD><<<g, 1024, 0, s>>>(d_a, d_tab, q, mu, bits, num, guard, 0u); break;
@@ -790,8 +790,8 @@ template <bool FWD>
 void launch_stage(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned length, unsigned num, unsigned q, unsigned mu, int bits,
                   hipStream_t s, const unsigned* guard)
 {
-    const size_t total = (size_t)num * (n / 2);
-    const unsigned g = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const size_t total = (size_t)num * (n / 2), cap = guard ? 1024 : 8192;      // (a guarded leg normally returns at once: its price is the dispatch)
+    const unsigned g = (unsigned)((total + 255) / 256 < cap ? (total + 255) / 256 : cap);
     k_ntt30_stage<FWD><<<g, 256, 0, s>>>(d_a, d_tab, n, length, q, mu, bits, num, guard);
 }
 
