@@ -191,5 +191,37 @@ int main(int argc, char** argv)
         printf("%s  num=%u  median %.4f ms  min %.4f ms  => %.3f M transforms/s  (%.1f%% of 15.26M)\n", which ? "inverse" : "forward", num,
                ts[ts.size() / 2], ts[0], num / (ts[ts.size() / 2] * 1e-3) / 1e6, num / (ts[ts.size() / 2] * 1e-3) / 15.26e6 * 100);
     }
+    // KB_STREAMS = k > 1: the batch split into k sub-batches, each transformed forward then inverse on a stream of its own, the k
+    // streams fed round-robin (the launch ramp of one sub-batch overlaps the tail of another); host clock over `reps` steps
+    if (getenv("KB_STREAMS") && atoi(getenv("KB_STREAMS")) > 1) {
+        const int k = atoi(getenv("KB_STREAMS"));
+        std::vector<hipStream_t> st(k);
+        for (auto& s : st) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        const unsigned per = num / k;
+        auto step = [&]() {
+            for (int s = 0; s < k; s++) {
+                (void)launch_fwd<LOGN>(HLSEL, a + (size_t)s * per * n, dtw, dp, per, 1, 0, st[s]);
+                (void)launch_inv<LOGN>(HLSEL, a + (size_t)s * per * n, dtw, dp, per, 1, 0, st[s]);
+            }
+        };
+        for (int rnd = 0; rnd < 3; rnd++) {
+            for (int i = 0; i < warm; i++) step();
+            CK(hipDeviceSynchronize());
+            for (int i = 0; i < 30; i++) step();          // (flows into the timed steps: no clock ramp)
+            // timed region between two events on stream 0 that every stream joins (wall time of the whole region, chip hot)
+            hipEvent_t j0[16], j1[16], es, ee;
+            CK(hipEventCreate(&es)); CK(hipEventCreate(&ee));
+            for (int s = 1; s < k; s++) { CK(hipEventCreateWithFlags(&j0[s], hipEventDisableTiming)); CK(hipEventRecord(j0[s], st[s])); CK(hipStreamWaitEvent(st[0], j0[s], 0)); }
+            CK(hipEventRecord(es, st[0]));
+            for (int s = 1; s < k; s++) CK(hipStreamWaitEvent(st[s], es, 0));
+            for (int i = 0; i < reps; i++) step();
+            for (int s = 1; s < k; s++) { CK(hipEventCreateWithFlags(&j1[s], hipEventDisableTiming)); CK(hipEventRecord(j1[s], st[s])); CK(hipStreamWaitEvent(st[0], j1[s], 0)); }
+            CK(hipEventRecord(ee, st[0]));
+            CK(hipDeviceSynchronize());
+            float worst = 0;
+            CK(hipEventElapsedTime(&worst, es, ee));
+            printf("streams=%d x %u polynomials: %.4f ms per step of %u pairs => %.3f M fwd+inv pairs/s\n", k, per, worst / reps, per * k, per * k / (worst / reps * 1e-3) / 1e6);
+        }
+    }
     return 0;
 }

@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(1024) k_ceiling(Out* out, unsigned long long w
     }
 }
 
+static int g_reps = 2;      // launches per measurement (the last one is reported); "sustain" mode: many long windows back to back
 template <int VARIANT, int PRIO>
 static void run(const char* name, int waves_per_simd, unsigned long long window_us)
 {
@@ -124,7 +125,7 @@ static void run(const char* name, int waves_per_simd, unsigned long long window_
     const size_t nw = (size_t)grid * block / 64;
     Out* d;
     CK(hipMalloc(&d, (nw + 1) * sizeof(Out)));
-    for (int rep = 0; rep < 2; rep++) {
+    for (int rep = 0; rep < g_reps; rep++) {
         hipLaunchKernelGGL((k_ceiling<VARIANT, PRIO>), dim3(grid), dim3(block), 0, 0, d, window_us * 100ull, 1152921504606584833ULL, 4443670208963ULL);
         CK(hipDeviceSynchronize());
     }
@@ -154,6 +155,16 @@ static void run(const char* name, int waves_per_simd, unsigned long long window_
 int main(int argc, char** argv)
 {
     unsigned long long win = argc > 1 ? strtoull(argv[1], nullptr, 10) : 3000;
+    if (argc > 2) {
+        // sustained mode: `reps` windows back to back (e.g. 20000 us x 100 = 2 s of full VALU issue), so that the figure is the one
+        // the chip holds under its power cap, not the first milliseconds at the boost clock; each line reports the LAST window
+        g_reps = atoi(argv[2]);
+        for (int i = 0; i < 3; i++) {
+            run<5, 0>("sustained: ct bfly, mad chain + fold U", 4, win);
+            run<6, 0>("sustained: gs bfly, mad chain", 4, win);
+        }
+        return 0;
+    }
     for (int w = 1; w <= 4; w++) run<0, 0>("ct bfly, VGPR twiddles", w, win);
     for (int w = 1; w <= 4; w++) run<1, 0>("ct bfly, SGPR twiddles", w, win);
     for (int w = 1; w <= 4; w++) run<2, 0>("gs bfly, VGPR twiddles", w, win);
