@@ -108,19 +108,22 @@ const mi355ntt_u64* mi355ntt_ctx_psiinv_tables(const mi355ntt_ctx* ctx);
  * Transforms on a context
  *
  * Stream capture.  Every launching entry point on a context or a BFV object (transforms, pointwise and fused products, the
- * BFV drivers single and batched, the samplers) only enqueues kernels on `stream`: no allocation, no synchronisation, no
- * host read, no memcpy after mi355ntt_ctx_create / mi355ntt_bfv_create.  They may therefore be called between
+ * BFV drivers single and batched, the samplers) only enqueues work on `stream`: no allocation, no synchronisation, no
+ * host read, no host-side memcpy after mi355ntt_ctx_create / mi355ntt_bfv_create (mi355ntt_bfv_keygen on a context created
+ * with MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES enqueues one device-to-device hipMemcpyAsync, which a capture records as a memcpy node).  They may therefore be called between
  * hipStreamBeginCapture and hipStreamEndCapture and the resulting hipGraph replayed (tools/lat_bench.cpp does, and checks
  * the results).  Not capture-safe: context / BFV creation and destruction, mi355ntt_ctx_probed_clock_mhz, and the
  * FIRST call of a raw-parameter entry point with a given table (it derives and caches a context: see below).
  *
  * n = 65536, batches from about one half-size transform per CU up: the forward transform runs two cooperating workgroups per
  * polynomial (they read each other's half of the input and exchange one "have read it" flag before storing in place; grid <=
- * one workgroup per CU, so it is resident as a whole).  The flag buffer is per device and belongs to one stream at a time: a
- * call on another stream while such a launch is still in flight, and any call on a capturing stream, runs the single-workgroup
- * launch instead (same words, ~10 % slower); the hand-over costs one hipEventRecord / hipEventQuery on the host.  A workgroup
- * whose partner does not become resident within tens of seconds aborts the kernel (hipErrorLaunchFailure at the next
- * synchronisation) rather than hang: that can only happen when another workload holds the device's CUs indefinitely.
+ * one workgroup per CU, so it is resident as a whole).  The flag buffer is per device, shared with the 30-bit path's n = 65536
+ * pair launches, and belongs to one stream at a time (at most one pair kernel of either word size is in flight per device): a
+ * call on another stream while such a launch is still in flight, any call on a capturing stream and any call on a stream created
+ * with a CU mask runs the single-workgroup launch instead (same words, ~10 % slower); the hand-over costs one hipEventRecord /
+ * hipEventQuery on the host.  A workgroup whose partner has not become resident after 30 s of wall clock (the GPU's constant
+ * 100 MHz counter, independent of the shader clock) aborts the kernel (hipErrorLaunchFailure at the next synchronisation) rather
+ * than hang: that can only happen when another workload holds the device's CUs indefinitely.
  * ---------------------------------------------------------------------------------------------- */
 /* forwardNTT (ntt_60bit.cuh:314-348): one polynomial, prime prime_idx */
 int mi355ntt_forward(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream stream);

@@ -105,6 +105,20 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
 hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
                               bool shared_b = false, unsigned group = 0);
 
+// ---- device-wide ownership of the pair flags (kernels_fast.hip): one pair kernel -- 60-bit k_forward15_pair or 30-bit k_ntt30x PAIR --
+// in flight per device.  pair_acquire: the slot when stream s may launch a pair kernel now (not capturing, every CU available to it, no
+// other stream's pair launch still in flight), else null: the caller runs its single-workgroup / stage-launch form.  Between
+// pair_acquire and pair_release (which records the launch on s) the caller holds a mutex: launch and nothing else.
+struct PairSlot;
+constexpr unsigned kPairFlagWords = 2048;               // zeroed 32-bit words; flags[2 pair + role], grid <= 1024 workgroups
+hipError_t pair_init_current_device();                  // allocates the current device's slot (idempotent)
+PairSlot* pair_acquire(hipStream_t s);
+void pair_release(PairSlot* slot, hipStream_t s);
+unsigned* pair_flags(PairSlot* slot);
+// watchdog of the spinning workgroups, in ticks of the 100 MHz constant clock (s_memrealtime): a partner that has not become resident
+// after this long means another tenant holds the CUs indefinitely; the kernel then aborts (hipErrorLaunchFailure) rather than hang
+constexpr unsigned long long kPairWatchdogTicks = 30ull * 100000000ull;      // 30 s
+
 // ---- the reference's 30-bit path (kernels_ntt30.hip): 32-bit words, single prime, `num` polynomials of n words ----
 // ninv_native: m^-1 mod q (m = n, or n / 2 at n = 2^16) when the call may run the native kernels, 0 = literal kernels only
 hipError_t ntt30_forward(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num, unsigned q, unsigned mu, int bits, unsigned ninv_native,

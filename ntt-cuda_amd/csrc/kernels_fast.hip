@@ -71,33 +71,48 @@ ModSet shifted(const ModSet& m, unsigned base, unsigned division)
     return r;
 }
 
-// ---- the device's pair flags (k_forward15_pair) --------------------------------------------------
-// One zeroed flag buffer per device, owned by ONE stream at a time: a launch of the pair kernel is followed by an event on its
-// stream, and another stream gets the buffer only once that event has completed (until then it runs the single-workgroup form).
-// So the pair kernels in flight on a device are ordered on one stream: their flags never mix, and workgroups spinning for a
-// partner can only be waiting for workgroups of their own launch that are next in line for a CU.  A capturing stream never takes
-// it (a graph may replay next to anything).  Created with the first n = 2^16 context on the device (fast_tables_create: no
-// allocation at call time).
+}  // namespace
+
+// ---- the device's pair flags (k_forward15_pair, k_ntt30x PAIR) ----------------------------------
+// One zeroed flag buffer per device, owned by ONE stream at a time and shared by BOTH word sizes: a launch of a pair kernel -- 60-bit
+// or 30-bit -- is followed by an event on its stream, and another stream gets the buffer only once that event has completed (until
+// then it runs the single-workgroup / stage-launch form).  So the pair kernels in flight on a device are ordered on one stream: their
+// flags never mix, and workgroups spinning for a partner can only be waiting for workgroups of their own launch that are next in
+// line for a CU (two pair kernels co-running on different streams could fill complementary CUs with partner-less spinners).  A
+// capturing stream never takes it (a graph may replay next to anything), nor does a stream restricted to part of the CUs (the grid
+// must be resident as a whole).  Created with the first n = 2^16 context on the device (fast_tables_create) or at the first 30-bit
+// n = 2^16 call (which allocates its per-stream scratch at that point anyway).
 struct PairSlot {
     unsigned* d_flags = nullptr;
     hipEvent_t done = nullptr;
     hipStream_t owner = nullptr;
     bool in_flight = false;
 };
+namespace {
 constexpr int kMaxDevices = 64;
 PairSlot g_pair[kMaxDevices];
 std::mutex g_pair_mutex;
 
-hipError_t pair_init_current_device()
+// every CU of the device available to stream s?  (hipExtStreamCreateWithCUMask / ROC_GLOBAL_CU_MASK restrict it)
+bool stream_has_all_cus(hipStream_t s)
 {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= kMaxDevices) return hipSuccess;           // (no slot: the single-workgroup form runs)
-    std::lock_guard<std::mutex> lock(g_pair_mutex);
-    PairSlot& p = g_pair[dev];
+    uint32_t mask[16] = {};
+    if (hipExtStreamGetCUMask(s, 16, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;                                               // (no mask information: the default is every CU)
+    }
+    unsigned bits = 0;
+    for (uint32_t m : mask) bits += (unsigned)__builtin_popcount(m);
+    return bits >= current_device_cus();
+}
+}  // namespace
+
+namespace {
+hipError_t pair_init_locked(PairSlot& p)
+{
     if (p.d_flags) return hipSuccess;
     unsigned* f = nullptr;
+    hipError_t e;
     if ((e = hipMalloc((void**)&f, kPairFlagWords * sizeof(unsigned))) != hipSuccess) return e;
     if ((e = hipMemset(f, 0, kPairFlagWords * sizeof(unsigned))) != hipSuccess ||
         (e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming)) != hipSuccess) {
@@ -107,8 +122,19 @@ hipError_t pair_init_current_device()
     p.d_flags = f;
     return hipSuccess;
 }
+}  // namespace
 
-// the slot when stream s may launch the pair kernel now, else null; pair_release records the launch
+hipError_t pair_init_current_device()
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipSuccess;           // (no slot: the single-workgroup form runs)
+    std::lock_guard<std::mutex> lock(g_pair_mutex);
+    return pair_init_locked(g_pair[dev]);
+}
+
+// the slot when stream s may launch a pair kernel now, else null; pair_release records the launch
 PairSlot* pair_acquire(hipStream_t s)
 {
     static const bool off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;      // (A/B measurements)
@@ -117,9 +143,11 @@ PairSlot* pair_acquire(hipStream_t s)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    if (!stream_has_all_cus(s)) return nullptr;
     g_pair_mutex.lock();
     PairSlot& p = g_pair[dev];
-    bool ok = p.d_flags != nullptr;
+    // (first use on this device without an n = 2^16 context -- the 30-bit path: allocated here, outside any capture)
+    bool ok = pair_init_locked(p) == hipSuccess && p.d_flags != nullptr;
     if (ok && p.in_flight && p.owner != s) {
         if (hipEventQuery(p.done) == hipSuccess) p.in_flight = false;
         else ok = false;
@@ -138,8 +166,8 @@ void pair_release(PairSlot* p, hipStream_t s)
     if (!p->in_flight) (void)hipStreamSynchronize(s);               // (no event: be sure instead)
     g_pair_mutex.unlock();
 }
+unsigned* pair_flags(PairSlot* p) { return p->d_flags; }
 
-}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,

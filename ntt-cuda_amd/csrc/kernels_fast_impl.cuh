@@ -479,11 +479,12 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
     // means the grid is not resident as a whole, which the launch rules exclude: abort the kernel, loudly, rather than hang or
     // store over words the partner still needs)
     auto wait_for_partner = [&]() {
-        unsigned spin = 0;
         unsigned* const partner_flag = flag_at(1u - role);
+        if (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > it) return;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // (watchdog by the constant 100 MHz clock, not by iterations)
         while (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spin == (1u << 25)) __builtin_trap();
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kPairWatchdogTicks) __builtin_trap();
         }
     };
     unsigned y = pair;
@@ -547,6 +548,7 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
         ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         wait_for_partner();
+        asm volatile("" ::: "memory");                    // (compiler-level order: nothing of the row store moves above the poll)
         wave_store_rows(v, slice, make_rsrc(a + (size_t)(2 * y + role) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
         it++;
         ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep);
@@ -1077,7 +1079,6 @@ MI355NTT_DECLARE_SIZE(15)
 bool fast_split_ok_16(unsigned num, int op, bool pair);   // (kernels_fast_n16.hip; op: 0 forward, 1 inverse, 2 fused product)
 hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                             hipStream_t s, unsigned* d_flags);      // (two workgroups per polynomial; d_flags: kPairFlagWords zeroed words)
-constexpr unsigned kPairFlagWords = 2048;
 bool fast_fwd_pair_ok_16(int hl);                         // (headroom classes 4 and 6)
 hipError_t fast_inv_split_16(int hl, u64* d_a, const u64* d_bhat, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,
                              unsigned base, hipStream_t s);       // (d_bhat: null, or the pointwise factor applied on the way in)

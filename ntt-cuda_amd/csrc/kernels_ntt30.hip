@@ -164,7 +164,7 @@ struct Scratch30 {
     u32 ninv, ninv_p;        // m^-1 mod q for the transform size m the kernel runs (n, or n/2 for the split) + companion
     u32 w1n[2], w1n_p[2];    // psiinv-table entry of the last GS stage (index A: 1, or 2 + h for half h) times ninv + companions
     unsigned pad[8];
-    unsigned flags[1024];    // k_ntt30x PAIR: one "have read it" counter per workgroup, zero between launches
+    unsigned reserved_[1024];   // (round 3 kept the PAIR flags here, per (device, stream); they are the device's now: kernels.hpp, pair_acquire)
     uint2 tw[65536];         // {w, floor(w * 2^32 / q)}
 };
 
@@ -522,7 +522,8 @@ __device__ __forceinline__ void inv_rounds32(u32 (&v)[32], const uint2* tw, BufR
 // half -- so the polynomial is read once from HBM (the second reader hits the L2) and written once, instead of twice each.
 // In place: a workgroup stores only after its partner has read the input underneath -- flags[2 pair + role] counts the
 // polynomials a workgroup has read completely (written behind the first exchange, polled in front of the stores, cleared on
-// exit); the buffer lives in the (device, stream) scratch, the grid is resident as a whole (one workgroup per CU).  As
+// exit); the buffer is the device's pair-flag slot (kernels.hpp: one pair kernel of either word size in flight per device), the grid is
+// resident as a whole (one workgroup per CU).  As
 // k_forward15_pair of the 60-bit path (kernels_fast_impl.cuh).
 template <int LOGN, bool FWD, bool PAIR = false>
 // (two workgroups of 1024 threads per CU would need 64 VGPRs per thread; without the prefetch set and with twiddle groups
@@ -639,12 +640,15 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
                 // drain), then: has the partner read the input under this result?  (long since, normally; a partner that never
                 // shows up -- tens of seconds -- means the grid is not resident as a whole: abort loudly rather than hang)
                 issue_loads_v(more ? y + stride : y, more);
-                unsigned spin = 0;
                 unsigned* const pf = flag_at(1u - h);
-                while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spin == (1u << 25)) __builtin_trap();
+                if (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // (watchdog by the constant 100 MHz clock)
+                    while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > kPairWatchdogTicks) __builtin_trap();
+                    }
                 }
+                asm volatile("" ::: "memory");            // (compiler-level order: no store of the result moves above the poll)
                 it++;
             }
 #if !defined(NTT30_NOMEM) && !defined(NTT30_NOSTORE)
@@ -675,15 +679,22 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
                     static_for<32>([&](auto rc) { __builtin_amdgcn_raw_buffer_store_b32(v[decltype(rc)::value], urs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 17); });
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();                      // every wave's words are in memory
+                    asm volatile("" ::: "memory");        // (compiler-level order: the count is published behind the drain and the barrier)
                     unsigned* const mf = flag_at(1u);
                     if (t == 0) __hip_atomic_store(mf, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    unsigned spin = 0;
                     unsigned* const pf = flag_at(1u);
-                    while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spin == (1u << 25)) __builtin_trap();      // (the partner never became resident: see the forward form)
+                    if (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > kPairWatchdogTicks) __builtin_trap();      // (the partner never became resident: see the forward form)
+                        }
                     }
+                    // compiler-level acquire: the (non-volatile) buffer loads of Y below must not be hoisted above the poll -- the
+                    // hardware issues them in order behind it, and they are sc0 sc1 (they do not hit a stale line)
+                    asm volatile("" ::: "memory");
+                    __atomic_signal_fence(__ATOMIC_ACQUIRE);
                     u32 yy[32];
                     static_for<32>([&](auto rc) { yy[decltype(rc)::value] = __builtin_amdgcn_raw_buffer_load_b32(urs, t * 4u, ((unsigned)decltype(rc)::value << G::B0) * 4u, 17); });
                     const uint2 w1 = tw[1];
@@ -767,9 +778,9 @@ inline unsigned pair_grid(unsigned halves)
     return grid < 2 || grid > 1024u ? 0u : grid;
 }
 template <bool FWD>
-void launch_native_pair(u32* d_a, Scratch30* sc, u32 q, unsigned halves, unsigned grid, hipStream_t s)
+void launch_native_pair(u32* d_a, Scratch30* sc, u32 q, unsigned halves, unsigned grid, hipStream_t s, unsigned* d_flags)
 {
-    k_ntt30x<15, FWD, true><<<grid, Geo<15>::T, 0, s>>>(d_a, sc, q, halves, 1u, sc->flags);
+    k_ntt30x<15, FWD, true><<<grid, Geo<15>::T, 0, s>>>(d_a, sc, q, halves, 1u, d_flags);
 }
 
 template <bool FWD>
@@ -835,19 +846,23 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     // n = 2^16, large enough calls (kPair30MinPolys*) outside stream capture (the flags of the scratch belong to live launches of
     // this stream only): the stage that couples the halves rides in a pair launch -- in its loads (forward) / behind its last
     // round (inverse, which then scales by n^-1 = m^-1 / 2 itself)
+    // The flags are the DEVICE's (kernels.hpp, pair_acquire), shared with the 60-bit pair kernel: at most one pair kernel of either
+    // word size is in flight per device, on one stream -- a call on another stream while one is still running, on a capturing stream or on
+    // a stream restricted to part of the CUs takes the stage launch below.
     unsigned pgrid = 0;
-    if (split && num >= (FWD ? kPair30MinPolysFwd : kPair30MinPolysInv)) {
-        static const bool pair_off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;     // (A/B measurements)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (!pair_off && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) pgrid = pair_grid(cnt);
+    PairSlot* slot = nullptr;
+    if (split && num >= (FWD ? kPair30MinPolysFwd : kPair30MinPolysInv) && (pgrid = pair_grid(cnt)) != 0) {
+        if ((slot = pair_acquire(s)) == nullptr) pgrid = 0;
     }
     const unsigned ninv_k = (pgrid && !FWD) ? (unsigned)(((u64)ninv_native * ((q + 1) / 2)) % q) : ninv_native;
-    k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_k, split, FWD ? 1u : 0u, sc, epoch);
     if (pgrid) {
-        launch_native_pair<FWD>(d_a, sc, q, cnt, pgrid, s);
+        k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_k, split, FWD ? 1u : 0u, sc, epoch);
+        launch_native_pair<FWD>(d_a, sc, q, cnt, pgrid, s, pair_flags(slot));
+        pair_release(slot, s);
         launch_literal<FWD>(d_a, n, d_tab, num, q, mu, bits, s, sc->guard, false);              // fallback leg: every stage
         return hipGetLastError();
     }
+    k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_k, split, FWD ? 1u : 0u, sc, epoch);
     if (split && FWD) launch_stage<true>(d_a, n, d_tab, 1, num, q, mu, bits, s, nullptr);       // stage 1 couples the two halves
     switch (m) {
     case 2048: launch_native<11, FWD>(d_a, sc, q, cnt, split, s); break;
