@@ -46,6 +46,72 @@ HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_TRANSFORM = 2 * 32768 * 8   # one in-place transform reads and writes the polynomial once
 
 
+def newest_profile(pattern):
+    """newest committed profile of a kind: `pattern` holds one %d for the round number (profiles/traffic_r%02d.json ...)"""
+    for rnd in range(9, 0, -1):
+        path = os.path.join(ROOT, "profiles", pattern % rnd)
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def rocprof_avg_ms(kernel):
+    """average launch duration of `kernel` in the newest committed `rocprofv3 --kernel-trace --stats` summary of this workload
+    (profiles/rNN_rocprofv3_summary_batch1024.txt, produced by tools/profile.sh 1024): (ms, file) or (None, None)"""
+    path = newest_profile("r%02d_rocprofv3_summary_batch1024.txt")
+    if not path:
+        return None, None
+    import re
+    for line in open(path):
+        if ("::" + kernel + "<") in line:
+            m = re.search(r"avg_ns=([0-9.]+)", line)
+            if m:
+                return float(m.group(1)) * 1e-6, os.path.relpath(path, ROOT)
+    return None, None
+
+
+class PowerSampler:
+    """rocm-smi package power / shader clock sampled in a background thread while a sustained run is in flight (the kernels run
+    at the package power cap: profiles/r04_power_cap_and_overlap.txt).  Samples: (seconds since start, sclk MHz, watts)."""
+
+    def __init__(self, period=0.25):
+        import threading
+        self.period, self.samples, self.stop_flag, self.cap = period, [], False, None
+        self.t0 = time.perf_counter()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _query(self, args):
+        return subprocess.run(["rocm-smi"] + args + ["--csv"], capture_output=True, text=True, timeout=10).stdout
+
+    def _run(self):
+        import re
+        while not self.stop_flag:
+            try:
+                row = [l for l in self._query(["--showpower", "--showclocks"]).splitlines() if l.startswith("card")]
+                if row:
+                    f = row[0].split(",")
+                    mhz = [int(x) for x in re.findall(r"\((\d+)Mhz\)", row[0])]
+                    self.samples.append((time.perf_counter() - self.t0, mhz[2] if len(mhz) > 2 else None, float(f[-1])))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        try:
+            import re
+            m = re.search(r"card\d+,([0-9.]+)", self._query(["--showmaxpower"]))
+            self.cap = float(m.group(1)) if m else None
+        except Exception:
+            self.cap = None
+        self.t0 = time.perf_counter()
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop_flag = True
+        self.thread.join(timeout=15)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -416,22 +482,22 @@ def main():
     alg_bytes = batch * BYTES_PER_TRANSFORM                       # per launch of either kernel
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9                  # GB/s
     traffic, traffic_source = None, None
-    for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload, " \
-                                 "FETCH_SIZE x 2 per the gfx950 calibration; not collected inside this run)" % tname
-            except Exception:
-                traffic = None
-            if traffic is not None:
-                break
+    tpath = newest_profile("traffic_r%02d.json")
+    if tpath:
+        try:
+            traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload, " \
+                             "FETCH_SIZE x 2 per the gfx950 calibration; not collected inside this run)" % os.path.relpath(tpath, ROOT)
+        except Exception:
+            traffic = None
+    # the same fraction from the committed rocprofv3 kernel trace (what a reader can reproduce from profiles/): rocprofv3 reads
+    # 5-6 % above the HIP-event time of the same kernel on the same box in every round
+    rp_ms, rp_file = rocprof_avg_ms(dom_name)
     # secondary (VALU) ceiling: issue cycles of the kernel's own instruction stream at the measured steady-state cost of
     # each instruction (tools/isa_cost.py over the shipped code object, tools/ubench_issue.hip), one polynomial per CU
     valu = {}
-    vpath = os.path.join(ROOT, "profiles", "valu_ceiling_r03.json")
-    if os.path.exists(vpath):
+    vpath = newest_profile("valu_ceiling_r%02d.json")
+    if vpath:
         try:
             valu = json.load(open(vpath))
         except Exception:
@@ -466,6 +532,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom_name,
                      "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "frac_rocprof": (alg_bytes / (rp_ms * 1e-3) / HBM_PEAK) if rp_ms else None,
+                     "frac_rocprof_source": ("%s: %s avg %.4f ms under rocprofv3 --kernel-trace (another run, another box; `frac` above is this run's "
+                                             "HIP-event time)" % (rp_file, dom_name, rp_ms)) if rp_ms else None,
                      "pair_frac_of_hbm_peak": pairs_per_s / world * 2 * BYTES_PER_TRANSFORM / HBM_PEAK,
                      "valu_ceiling_transforms_per_s": valu_ceiling,
                      "frac_of_valu_ceiling": (batch / (dom_ms * 1e-3) / valu_ceiling) if valu_ceiling else None,
@@ -474,8 +543,10 @@ def main():
                      "in_kernel_clock_mhz": {"k_forward15": fwd_clock_mhz, "k_inverse15": inv_clock_mhz,
                                              "how": "a clock probe (one wave: s_memtime shader cycles counted over 20 us of the 100 MHz s_memrealtime) enqueued right behind the K back-to-back launches the kernel time is taken from"},
                      "compute_units": cus,
-                     "valu_ceiling_source": "profiles/valu_ceiling_r03.json (tools/valu_ceiling.py: measured issue cycles per instruction summed over the shipped "
-                                            "kernels' polynomial loops) x compute_units x in_kernel_clock_mhz of this run"},
+                     "valu_ceiling_source": "%s (tools/valu_ceiling.py: measured issue cycles per instruction summed over the shipped "
+                                            "kernels' polynomial loops; a CPU test fails when it drifts from the sources) x compute_units x in_kernel_clock_mhz "
+                                            "of this run.  NOT reachable together with the memory traffic: the package sits at its power cap "
+                                            "(extras.power_sustained, profiles/r04_power_cap_and_overlap.txt)" % (os.path.relpath(vpath, ROOT) if vpath else None)},
         "kernel_ms": {"k_forward15": fwd_ms, "k_inverse15": inv_ms, "step_by_events": step_ms_events},
         "rounds": {"what": "%d rounds of %d forward+inverse steps each, queued back to back, HIP events between rounds (BASELINE.md 2)" % (ROUNDS, ROUND_STEPS),
                    "pairs_per_s_median": world * batch / (round_ms[ROUNDS // 2] * 1e-3), "pairs_per_s_best": world * batch / (round_ms[0] * 1e-3),
@@ -501,24 +572,28 @@ def main():
             ntt.forwardNTT_batch(a, n, tabs_f, batch, P, m)
             ntt.inverseNTT_batch(a, n, tabs_i, batch, P, m)
 
-        def pairs_rate(fn, reps, prewarm=100):
-            # same discipline as the headline: an untimed pre-warm that flows straight into the timed launches (every host
-            # synchronisation lets the clocks drop; a region timed right after one reads up to 30 % low), HIP events around it
-            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        def pairs_rate(fn, reps, prewarm=300):
+            # same discipline as the headline: an untimed pre-warm that flows straight into the timed launches -- every host
+            # synchronisation (and already a few milliseconds of host work with the queue empty) lets the clocks drop, and they take
+            # ~100 steps to come back: tools/raw_trusted_diag.py -- then THREE timed chunks between events, median reported (a long
+            # train of unsynchronised launches occasionally stalls once while the runtime recycles its kernel-argument pool)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             for _ in range(prewarm):
                 fn()
-            r0.record()
-            for _ in range(reps):
-                fn()
-            r1.record()
+            ev[0].record()
+            for c in range(3):
+                for _ in range(reps):
+                    fn()
+                ev[c + 1].record()
             torch.cuda.synchronize()
-            return batch * reps / (r0.elapsed_time(r1) * 1e-3)
+            ms = sorted(ev[c].elapsed_time(ev[c + 1]) for c in range(3))
+            return batch * reps / (ms[1] * 1e-3)
 
-        raw_checked = pairs_rate(lambda: raw_step(mod), args.steps)
+        raw_checked = pairs_rate(lambda: raw_step(mod), max(40, args.steps))
         assert torch.equal(a, a0)
         ntt.raw_trust_tables(n, tabs_f, mod)
         ntt.raw_trust_tables(n, tabs_i, mod, inverse=True)
-        raw_trusted = pairs_rate(lambda: raw_step(mod), args.steps)
+        raw_trusted = pairs_rate(lambda: raw_step(mod), max(40, args.steps))
         assert torch.equal(a, a0)
         mu_lit = mod.mu.copy()
         mu_lit[0] -= 1
@@ -529,7 +604,7 @@ def main():
             ntt.forwardNTT_batch(scratch, n, tabs_f, batch, P, lit)
             ntt.inverseNTT_batch(scratch, n, tabs_i, batch, P, lit)
 
-        raw_literal = pairs_rate(lit_step, max(2, args.steps // 10), prewarm=10)
+        raw_literal = pairs_rate(lit_step, max(4, args.steps // 10), prewarm=20)
         del scratch
         out["raw_api"] = {"raw_api_pairs_per_s": raw_checked, "raw_api_trusted_pairs_per_s": raw_trusted,
                           "raw_literal_pairs_per_s": raw_literal,
@@ -569,6 +644,80 @@ def main():
                    "vs_forward_plus_inverse_ms": fwd_ms + inv_ms,
                    "units": "fraction of 8.0 TB/s on 1 310 720 B (SURVEY 8d graded unit) and on 786 432 B (what one fused pass moves)"}
         del bN, bhN
+
+        # ---- the HBM-streaming state: 4096 and 8192 polynomials (configs[3]'s global batch resident on ONE GPU: 2 GiB of 288) ----
+        # The headline batch (1024 polynomials = 256 MiB) is the size of the memory-side cache, and the inverse walks the batch
+        # downwards to start on what the forward left there; these batches stream from HBM.
+        def large_batch(num):
+            try:
+                big = synth_recipe(torch, ctx, num, n, dev, seed_base=9_000_001)
+                bigb = synth_recipe(torch, ctx, num, n, dev, seed_base=19_000_001)
+                reps, warm = max(6, 20480 // num), max(12, 61440 // num)
+
+                def rate(fn):
+                    for _ in range(warm):
+                        fn()
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / reps
+
+                def pair_():
+                    ctx.forward_batch(big, num)
+                    ctx.inverse_batch(big, num)
+
+                ref = big[:8].clone()
+                p_ms = rate(pair_)
+                ok = bool(torch.equal(big[:8], ref))
+                f_ms = rate(lambda: ctx.forward_batch(big, num))
+                i_ms = rate(lambda: ctx.inverse_batch(big, num))
+                m_ms = rate(lambda: ctx.polymul_batch(big, bigb, num))
+                del big, bigb
+                slow = max(f_ms, i_ms)
+                return {"batch": num, "bytes": num * n * 8, "pairs_per_s": num / (p_ms * 1e-3), "pair_ms": p_ms, "forward_ms": f_ms, "inverse_ms": i_ms,
+                        "fused_product_ms": m_ms, "fused_products_per_s": num / (m_ms * 1e-3), "round_trip_ok": ok,
+                        "ms_per_1024": {"forward": f_ms * 1024 / num, "inverse": i_ms * 1024 / num, "pair": p_ms * 1024 / num, "fused_product": m_ms * 1024 / num},
+                        "frac": num * BYTES_PER_TRANSFORM / (slow * 1e-3) / HBM_PEAK,
+                        "pair_frac_of_hbm_peak": num / (p_ms * 1e-3) * 2 * BYTES_PER_TRANSFORM / HBM_PEAK,
+                        "how": "HIP events around %d back-to-back launches behind %d untimed ones; frac = algorithmic bytes of the slower of the two "
+                               "transform kernels / its time / 8 TB/s" % (reps, warm)}
+            except Exception as exc:        # never let an optional leg break the contract line
+                return {"batch": num, "error": repr(exc)}
+
+        big4096, big8192 = large_batch(4096), large_batch(8192)
+
+        # ---- sustained run with package power / shader clock sampled (the kernels sit at the package power cap) ----
+        power = None
+        try:
+            with PowerSampler() as ps:
+                # ~3 s of headline steps in chunks of 200, at most two chunks queued (the host waits for the event of the chunk before
+                # the previous one: the GPU never runs dry, the queue never grows)
+                chunks = max(3, int(3.0 / (200 * elapsed / args.steps)))
+                cev = [torch.cuda.Event() for _ in range(chunks)]
+                t_s = time.perf_counter()
+                for c in range(chunks):
+                    for _ in range(200):
+                        step()
+                    cev[c].record()
+                    if c >= 2:
+                        cev[c - 2].synchronize()
+                torch.cuda.synchronize()
+                el_s = time.perf_counter() - t_s
+                nst = 200 * chunks
+            mid = [x for x in ps.samples if 0.8 < x[0] < el_s]
+            if mid:
+                power = {"pairs_per_s": batch * nst / el_s, "seconds": el_s, "samples": len(mid),
+                         "package_power_w_mean": sum(x[2] for x in mid) / len(mid), "package_power_w_max": max(x[2] for x in mid),
+                         "sclk_mhz_mean": (sum(x[1] for x in mid if x[1]) / max(1, len([x for x in mid if x[1]]))),
+                         "power_cap_w": ps.cap,
+                         "how": "rocm-smi --showpower --showclocks every 0.25 s during %.1f s of back-to-back headline steps (first 0.8 s dropped)" % el_s}
+            else:
+                power = {"error": "no rocm-smi samples"}
+        except Exception as exc:
+            power = {"error": repr(exc)}
+        assert torch.equal(a, a0)
         one = synth(torch, 1, n, Q60[:1], dev, seed=9)
 
         def lat(fn):
@@ -635,6 +784,8 @@ def main():
             n16 = {"error": repr(exc)}
         out["extras"] = {"config2_fused_polymul_batch256_per_s": 256 / (mul_ms * 1e-3), "config2_fused_polymul_ms": mul_ms,
                          "n65536_batch512": n16,
+                         "n32768_batch4096": big4096, "n32768_batch8192": big8192,
+                         "power_sustained": power,
                          "fused_polymul_headline_batch": polymul,
                          "latency_compiled_cpp": cpp_lat,
                          "config1_batch1_fwd_inv_pair_us": pair_us, "config1_batch1_forward_us": fwd_us,
@@ -677,17 +828,15 @@ def main():
                                  "what": "rank-0-resident batch: chunked scatter, forward+inverse per shard, gather back to rank 0"}
         except Exception as exc:            # never let the optional leg break the contract line
             out["end_to_end"] = {"error": repr(exc)}
-    if rank == 0 and not args.no_cpu_baseline:
-        # rank 0's host cores, after the timed region (the other ranks wait at the final barrier): also for N > 1
-        out["cpu_baseline"] = cpu_baseline(n, Q60, PSI60)
-    elif rank == 0:
-        out["cpu_baseline"] = None
     ctx.close()
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1:
-        dist.barrier()              # rank 0 may have spent a while in the CPU leg
+        # every rank leaves the collective layer BEFORE rank 0's multi-second CPU leg: nobody sits in an RCCL barrier meanwhile
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # rank 0's host cores, after the timed region and after the process group is gone: also for N > 1
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n, Q60, PSI60)
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

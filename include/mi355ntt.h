@@ -163,6 +163,38 @@ int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, co
                                   unsigned num, unsigned division, unsigned group, mi355ntt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: shards of a batch.  The reference is single-GPU; its batch kernels let no two polynomials interact
+ * (blockIdx.y is the data offset y*n and the modulus y % division, nothing else: ntt_60bit.cuh:391,404,422), so a batch shards
+ * into contiguous ranges of WHOLE polynomials whose starts are multiples of `division`, one replicated context per device, no
+ * collective on the data path.  Two forms: one process per GPU over torch.distributed / RCCL (ntt_cuda_amd/shard.py), and ONE
+ * process driving several devices through the object below (peer copies over xGMI for a root-resident batch).
+ * ---------------------------------------------------------------------------------------------- */
+/* the partitioning rule: shard `rank` of `world` = polynomials [*first, *first + *count); groups of `division` polynomials dealt as
+ * evenly as possible, a ragged tail (num % division) with the last rank */
+int mi355ntt_shard_range(unsigned num, unsigned division, unsigned rank, unsigned world, unsigned* first, unsigned* count);
+
+typedef struct mi355ntt_shards mi355ntt_shards;
+enum { MI355NTT_OP_FORWARD = 0, MI355NTT_OP_INVERSE = 1, MI355NTT_OP_FORWARD_INVERSE = 2, MI355NTT_OP_POLYMUL = 3 };
+/* ctxs[r]: the context of shard r (same n and primes everywhere; normally one per device, several on one device are allowed --
+ * "logical shards").  ctxs[0]'s device is the ROOT.  max_polys_per_piece > 0 allocates, on every non-root lane, three staging
+ * buffers of that many polynomials for mi355ntt_shards_scatter_transform_gather (0: device-resident shards only).  Creates three
+ * streams per lane; enables peer access towards the root where the hardware offers it. */
+int mi355ntt_shards_create(mi355ntt_shards** out, const mi355ntt_ctx* const* ctxs, unsigned world, unsigned max_polys_per_piece);
+int mi355ntt_shards_destroy(mi355ntt_shards* shards);
+unsigned mi355ntt_shards_world(const mi355ntt_shards* shards);
+/* Device-resident shards: d_shard[r] (on ctxs[r]'s device) holds the polynomials mi355ntt_shard_range names for r; every shard is
+ * transformed in place, all devices concurrently.  d_bhat_shard: per-shard second operands for MI355NTT_OP_POLYMUL, else NULL.
+ * `stream` (of the root device) is the fork and join point: the launches see what was enqueued on it before the call, what is
+ * enqueued on it afterwards sees every shard done.  No host synchronisation. */
+int mi355ntt_shards_transform(mi355ntt_shards* shards, int op, mi355ntt_u64* const* d_shard, const mi355ntt_u64* const* d_bhat_shard,
+                              unsigned num, unsigned division, mi355ntt_stream stream);
+/* Root-resident batch d_full [num][n] on the root device: every other lane receives its shard in up to `chunks` pieces by peer
+ * copies, transforms piece k while piece k + 1 arrives and piece k - 1 returns into d_full; the root transforms its own shard in
+ * place.  MI355NTT_OP_FORWARD / _INVERSE / _FORWARD_INVERSE.  Same fork / join contract on `stream`. */
+int mi355ntt_shards_scatter_transform_gather(mi355ntt_shards* shards, int op, mi355ntt_u64* d_full, unsigned num, unsigned division,
+                                             unsigned chunks, mi355ntt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement helpers (no reference counterpart: the reference's programs draw inputs on the host, 60bit_ntt_test.cu:52-60)
  * ---------------------------------------------------------------------------------------------- */
 /* Synthetic inputs of the benchmark recipe, generated on the context's device: polynomial y of d_a [num][n] receives the
@@ -175,6 +207,10 @@ int mi355ntt_synth_splitmix(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned
  * enqueued in front of the probe left the chip at (bench.py prices its VALU ceiling with it; the power management moves the clock
  * over milliseconds).  The second call synchronises the device.  0 until a probe has run. */
 int mi355ntt_ctx_clock_probe(const mi355ntt_ctx* ctx, mi355ntt_stream stream);
+/* Foreign load for tests and measurements: enqueues on `stream` a kernel of `workgroups` workgroups that each hold one whole CU (1024
+ * threads, 144 KiB of LDS -- the footprint of the n = 2^15 kernels) for `microseconds` and touch no memory.  tests/test_gpu_stress.py
+ * uses it to take half of the CUs away from under the cooperating-workgroup launches (they must come out slow, not wrong). */
+int mi355ntt_ctx_occupy(const mi355ntt_ctx* ctx, unsigned workgroups, unsigned microseconds, mi355ntt_stream stream);
 int mi355ntt_ctx_probed_clock_mhz(const mi355ntt_ctx* ctx, double* mhz);
 
 /* ------------------------------------------------------------------------------------------------

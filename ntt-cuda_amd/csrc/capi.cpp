@@ -430,6 +430,14 @@ int mi355ntt_ctx_clock_probe(const mi355ntt_ctx* c, mi355ntt_stream s)
     return MI355NTT_OK;
 }
 
+int mi355ntt_ctx_occupy(const mi355ntt_ctx* c, unsigned workgroups, unsigned microseconds, mi355ntt_stream s)
+{
+    if (!c || workgroups > 65535u || microseconds > 10000000u) return MI355NTT_EINVAL;
+    ON_CTX_DEVICE(c);
+    HIP_TRY(fast_occupy(workgroups, microseconds, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+
 int mi355ntt_ctx_probed_clock_mhz(const mi355ntt_ctx* c, double* mhz)
 {
     if (!c || !mhz) return MI355NTT_EINVAL;

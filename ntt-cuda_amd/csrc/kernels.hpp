@@ -97,6 +97,8 @@ void fast_tables_destroy(FastTables* t);
 // measurement helper: a stream-ordered clock probe (20 us) and the shader clock it measured (the read synchronises)
 hipError_t fast_clock_probe(const FastTables& t, hipStream_t s);
 hipError_t fast_probed_clock_mhz(const FastTables& t, double* mhz);
+// test / measurement helper: `workgroups` whole CUs held for `microseconds` (k_occupy), stream-ordered, touches no memory
+hipError_t fast_occupy(unsigned workgroups, unsigned microseconds, hipStream_t s);
 // polynomial y of the batch uses prime (prime_base + y % division)
 hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);
 hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s);

@@ -59,6 +59,18 @@ __global__ void __launch_bounds__(64) k_clock_probe(unsigned long long* __restri
     }
 }
 
+// Foreign load for tests and measurements (mi355ntt_ctx_occupy): `workgroups` workgroups of 1024 threads holding 144 KiB of LDS each --
+// one whole CU apiece, like the n = 2^15 kernels -- spin for `ticks` of the 100 MHz constant clock and exit.  Touches no memory.
+__global__ void __launch_bounds__(1024) k_occupy(unsigned long long ticks, unsigned* sink)
+{
+    __shared__ unsigned long long hold[18432];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    hold[threadIdx.x] = t0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    __syncthreads();
+    if (hold[(threadIdx.x + 1) & 1023] == 1 && sink) sink[0] = 1;      // (never true: keeps the LDS allocation alive)
+}
+
 ModSet shifted(const ModSet& m, unsigned base, unsigned division)
 {
     ModSet r;
@@ -295,6 +307,13 @@ hipError_t fast_clock_probe(const FastTables& t, hipStream_t s)
 {
     if (!t.d_primes_alloc) return hipErrorInvalidValue;
     k_clock_probe<<<1, 64, 0, s>>>(static_cast<unsigned long long*>(t.d_primes_alloc));
+    return hipGetLastError();
+}
+
+hipError_t fast_occupy(unsigned workgroups, unsigned microseconds, hipStream_t s)
+{
+    if (workgroups == 0) return hipSuccess;
+    k_occupy<<<workgroups, 1024, 0, s>>>((unsigned long long)microseconds * 100ull, nullptr);
     return hipGetLastError();
 }
 

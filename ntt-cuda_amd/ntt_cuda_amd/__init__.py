@@ -79,8 +79,15 @@ _SIGNATURES = {
     "mi355ntt_polymul_batch_shared": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp]),
     "mi355ntt_bfv_encrypt_batch": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_uint, vp]),
     "mi355ntt_bfv_decrypt_batch": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, vp]),
+    "mi355ntt_shard_range": (ctypes.c_int, [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, u32p, u32p]),
+    "mi355ntt_shards_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint]),
+    "mi355ntt_shards_destroy": (ctypes.c_int, [vp]),
+    "mi355ntt_shards_world": (ctypes.c_uint, [vp]),
+    "mi355ntt_shards_transform": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, vp]),
+    "mi355ntt_shards_scatter_transform_gather": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, vp]),
     "mi355ntt_synth_splitmix": (ctypes.c_int, [vp, vp, ctypes.c_uint, ctypes.c_uint, u64, vp]),
     "mi355ntt_ctx_clock_probe": (ctypes.c_int, [vp, vp]),
+    "mi355ntt_ctx_occupy": (ctypes.c_int, [vp, ctypes.c_uint, ctypes.c_uint, vp]),
     "mi355ntt_ctx_probed_clock_mhz": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
     "mi355ntt_raw_cache_clear": (ctypes.c_int, []),
     "mi355ntt_raw_uses_fast_kernels": (ctypes.c_int, [ctypes.c_uint, vp, ctypes.c_int, ctypes.c_uint, u64p, u64p, u32p]),
@@ -363,6 +370,10 @@ class NTTContext:
         """enqueue a clock probe on the stream: shader cycles counted over 20 us of the 100 MHz clock"""
         _check(lib().mi355ntt_ctx_clock_probe(self._h, _stream(stream)), "mi355ntt_ctx_clock_probe")
 
+    def occupy(self, workgroups, microseconds, stream=None):
+        """foreign load: `workgroups` whole CUs held for `microseconds` on `stream` (mi355ntt_ctx_occupy)"""
+        _check(lib().mi355ntt_ctx_occupy(self._h, int(workgroups), int(microseconds), _stream(stream)), "mi355ntt_ctx_occupy")
+
     def probed_clock_mhz(self):
         """shader clock measured by the last probe: what the launches enqueued in front of it left the chip at (synchronises); 0.0 = none"""
         v = ctypes.c_double(0.0)
@@ -376,6 +387,64 @@ class NTTContext:
         groups = -(-int(num) // g) if g else 1
         _check(lib().mi355ntt_polymul_batch_shared(self._h, self._p(a, num), self._p(bhat, d * groups), int(num), d, g, _stream(stream)),
                "mi355ntt_polymul_batch_shared")
+
+
+OP_FORWARD, OP_INVERSE, OP_FORWARD_INVERSE, OP_POLYMUL = 0, 1, 2, 3     # MI355NTT_OP_*
+
+
+def shard_range(num, division, rank, world):
+    """mi355ntt_shard_range: (first polynomial, count) of shard `rank` of `world` (host only; the C-ABI twin of shard.shard_range)"""
+    first, count = ctypes.c_uint(), ctypes.c_uint()
+    _check(lib().mi355ntt_shard_range(int(num), int(division), int(rank), int(world), ctypes.byref(first), ctypes.byref(count)),
+           "mi355ntt_shard_range")
+    return first.value, count.value
+
+
+class ShardSet:
+    """mi355ntt_shards: several devices (or several logical shards of one device) driven from ONE process -- device-resident shards
+    transformed concurrently, or a root-resident batch scattered by peer copies, transformed and gathered (include/mi355ntt.h)."""
+
+    def __init__(self, contexts, max_polys_per_piece=0):
+        self.contexts = list(contexts)          # (kept alive: the object holds their handles)
+        arr = (vp * len(self.contexts))(*[c._h for c in self.contexts])
+        self._h = vp()
+        _check(lib().mi355ntt_shards_create(ctypes.byref(self._h), arr, len(self.contexts), int(max_polys_per_piece)), "mi355ntt_shards_create")
+        self.n = self.contexts[0].n
+        self.num_primes = self.contexts[0].num_primes
+
+    @property
+    def world(self):
+        return int(lib().mi355ntt_shards_world(self._h))
+
+    def transform(self, op, shards, num, division=None, bhat=None, stream=None):
+        """shards[r]: tensor on contexts[r]'s device holding the polynomials shard_range(num, division, r, world) names"""
+        division = int(division or self.num_primes)
+        ptrs, bptrs = [], []
+        for r, t in enumerate(shards):
+            _, c = shard_range(num, division, r, len(shards))
+            ptrs.append(_ptr_n(t, c * self.n, self.contexts[r].device) if c else None)
+            if bhat is not None:
+                bptrs.append(_ptr_n(bhat[r], c * self.n, self.contexts[r].device) if c else None)
+        arr = (vp * len(ptrs))(*ptrs)
+        barr = (vp * len(bptrs))(*bptrs) if bhat is not None else None
+        _check(lib().mi355ntt_shards_transform(self._h, int(op), arr, barr, int(num), division, _stream(stream)), "mi355ntt_shards_transform")
+
+    def scatter_transform_gather(self, op, full, num, division=None, chunks=4, stream=None):
+        """full: [num, n] tensor on contexts[0]'s device, transformed in place through every lane"""
+        division = int(division or self.num_primes)
+        _check(lib().mi355ntt_shards_scatter_transform_gather(self._h, int(op), _ptr_n(full, int(num) * self.n, self.contexts[0].device), int(num),
+                                                              division, int(chunks), _stream(stream)), "mi355ntt_shards_scatter_transform_gather")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mi355ntt_shards_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # --------------------------------------------------------------------------- reference-named raw API

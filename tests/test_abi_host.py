@@ -136,13 +136,32 @@ def test_library_build_rejects_experiment_switches(tmp_path):
     assert lab.returncode == 0, lab.stderr[-2000:]
 
 
-def test_n15_kernels_use_no_scratch():
+@pytest.fixture(scope="module")
+def n15_compile(tmp_path_factory):
+    """ONE compilation of kernels_fast_n15.hip (about two minutes) serves the scratch check and the VALU-ceiling drift check:
+    compiler remarks on stdout of tools/kernel_resources.py, the gfx950 assembly beside it."""
+    tool = os.path.join(ROOT, "tools", "kernel_resources.py")
+    src = os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip")
+    asm = str(tmp_path_factory.mktemp("n15") / "n15.s")
+    r = subprocess.run([sys.executable, tool, src, "15", "--require-no-scratch", "15", "--asm-out", asm], capture_output=True, text=True, timeout=1200)
+    return r, asm
+
+
+def test_n15_kernels_use_no_scratch(n15_compile):
     """Every n = 2^15 kernel instantiation (18 persistent + 30 small-batch: headroom class x near / general prime) fits its
     128-VGPR budget without scratch memory (compiler remarks; tools/kernel_resources.py).  Round 2 shipped the general-prime
     inverse and fused kernels with 28-104 bytes of scratch per lane."""
-    tool = os.path.join(ROOT, "tools", "kernel_resources.py")
-    src = os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip")
-    r = subprocess.run([sys.executable, tool, src, "15", "--require-no-scratch", "15"], capture_output=True, text=True, timeout=900)
+    r, _ = n15_compile
     rows = [l for l in r.stdout.splitlines() if "VGPRs" in l]
     assert r.returncode == 0, r.stdout[-3000:]
     assert len(rows) == 48, len(rows)
+
+
+def test_valu_ceiling_profile_matches_shipped_kernels(n15_compile):
+    """profiles/valu_ceiling_r04.json (the VALU ceiling bench.py prints beside the HBM roofline) is recomputed from the shipped
+    sources: instruction counts of the three polynomial loops exactly, issue cycles to 1e-6.  A kernel change without
+    `python3 tools/valu_ceiling.py` in the same commit fails here (round 3 shipped a stale k_polymul15 entry)."""
+    _, asm = n15_compile
+    assert os.path.exists(asm) and os.path.getsize(asm) > 1 << 20
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_ceiling.py"), "--asm", asm, "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -1,0 +1,117 @@
+"""GPU, round 4: the single-process multi-device driver of the C ABI (mi355ntt_shards_*) with logical shards on the one device, RCCL
+initialised and used once under test (torch.distributed backend "nccl" at world size 1: barrier, MAX all-reduce, a self send/recv,
+scatter_transform_gather), the stand-alone element-wise wrappers of poly_arithmetic.cuh:312-352, per-prime literal routing, and the
+61-bit kernel class."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import params as P
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _residues(torch, gpu, num, n, qs, seed):
+    g = torch.Generator(device=gpu).manual_seed(seed)
+    qcol = torch.tensor(np.array(qs, dtype=np.uint64).view(np.int64), device=gpu)[torch.arange(num, device=gpu) % len(qs)].unsqueeze(1)
+    a = torch.randint(0, 1 << 60, (num, n), dtype=torch.int64, device=gpu, generator=g)
+    return torch.where(a >= qcol, a - qcol, a).contiguous()
+
+
+@pytest.mark.parametrize("num,world", [(1024, 4), (1023, 8), (6, 4)])
+def test_shardset_logical_shards_equal_whole_batch(native, oracle, gpu, num, world):
+    """SURVEY 8(e) through the C ABI: `world` lanes (one context each, all on cuda:0 -- logical shards) give the words of the
+    whole-batch call, for device-resident shards (forward, inverse, fused product) and for a root-resident batch dealt out in pieces
+    (more pieces than staging buffers: the ring wraps), also with a ragged tail and with empty shards."""
+    import torch
+    n, qs, psis = 32768, P.Q60, P.PSI60
+    ctxs = [native.NTTContext(n, qs, psis) for _ in range(world)]
+    sh = native.ShardSet(ctxs, max_polys_per_piece=64)
+    assert sh.world == world
+    a, b = _residues(torch, gpu, num, n, qs, 7 + num), _residues(torch, gpu, num, n, qs, 8 + num)
+    whole_f = a.clone()
+    ctxs[0].forward_batch(whole_f, num)
+    bh = b.clone()
+    ctxs[0].forward_batch(bh, num)
+    whole_m = a.clone()
+    ctxs[0].polymul_batch(whole_m, bh, num)
+    # device-resident shards: separate tensors per lane
+    ranges = [native.shard_range(num, 4, r, world) for r in range(world)]
+    assert sum(c for _, c in ranges) == num
+    parts = [a[s:s + c].clone() if c else torch.empty((0, n), dtype=torch.int64, device=gpu) for s, c in ranges]
+    sh.transform(native.OP_FORWARD, parts, num)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts), whole_f)
+    sh.transform(native.OP_INVERSE, parts, num)
+    assert torch.equal(torch.cat(parts), a)               # (the join is stream-ordered: torch.cat runs on the current stream)
+    bparts = [bh[s:s + c].clone() if c else torch.empty((0, n), dtype=torch.int64, device=gpu) for s, c in ranges]
+    sh.transform(native.OP_POLYMUL, parts, num, bhat=bparts)
+    assert torch.equal(torch.cat(parts), whole_m)
+    # root-resident batch: scatter / transform / gather in place, pieces of at most 64 polynomials
+    full = a.clone()
+    sh.scatter_transform_gather(native.OP_FORWARD, full, num, chunks=5)
+    assert torch.equal(full, whole_f)
+    sh.scatter_transform_gather(native.OP_INVERSE, full, num, chunks=2)
+    assert torch.equal(full, a)
+    for _ in range(3):                                    # back to back: the staging ring is reused across calls
+        sh.scatter_transform_gather(native.OP_FORWARD_INVERSE, full, num, chunks=3)
+    assert torch.equal(full, a)
+    # a sample against the oracle
+    prm = oracle.Params(n, qs, psis)
+    for y in (0, num - 1):
+        assert np.array_equal(native.to_host(whole_f[y].contiguous()), oracle.forward(native.to_host(a[y].contiguous()), prm, y % 4))
+    with pytest.raises(native.NTTError):
+        sh.scatter_transform_gather(native.OP_POLYMUL, full, num)
+    sh.close()
+    for c in ctxs:
+        c.close()
+
+
+_NCCL_CHILD = r"""
+import os, sys, socket
+sys.path.insert(0, os.path.join(ROOT, "ntt-cuda_amd")); sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+import ntt_cuda_amd as ntt
+from ntt_cuda_amd import shard
+from bench import Q60, PSI60
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+dist.barrier()
+assert shard.max_over_ranks(1.25, device=dev) == 1.25                      # the bench's MAX reduction, on the GPU through RCCL
+x = torch.arange(1 << 16, dtype=torch.int64, device=dev); y = torch.zeros_like(x)
+for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, x, 0), dist.P2POp(dist.irecv, y, 0)]):     # RCCL send/recv (to itself)
+    q.wait()
+torch.cuda.synchronize()
+assert torch.equal(x, y)
+n, num = 32768, 64
+ctx = ntt.NTTContext(n, Q60, PSI60)
+full = torch.empty((num, n), dtype=torch.int64, device=dev); ctx.synth_splitmix(full, num, 1)
+ref = full.clone()
+def tf(piece, count):
+    ctx.forward_batch(piece, count); ctx.inverse_batch(piece, count)
+got = shard.scatter_transform_gather(full, num, n, 4, tf, chunks=4, src=0, device=dev, inplace=True)
+torch.cuda.synchronize()
+assert got.data_ptr() == full.data_ptr() and torch.equal(full, ref)
+loc = shard.scatter_batch(full, num, n, 4, src=0, device=dev)
+back = shard.gather_batch(loc, num, n, 4, dst=0)
+assert torch.equal(back, ref)
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL-OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+"""
+
+
+def test_rccl_is_initialised_and_used_once_world_size_1(native, gpu):
+    """No multi-GPU node is available to this build, so RCCL cannot move a shard between GPUs here; what one GPU allows is run:
+    torch.distributed backend "nccl" (= RCCL) at world size 1 -- process group on cuda:0, barrier, the bench's MAX all-reduce, a
+    self send/recv through batch_isend_irecv, shard.scatter_transform_gather / scatter_batch / gather_batch on CUDA tensors."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + _NCCL_CHILD], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "NCCL-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]

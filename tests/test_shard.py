@@ -28,6 +28,27 @@ def test_shard_ranges_cover_and_respect_division():
         shard_range(8, 0, 0, 1)
 
 
+def test_c_abi_shard_range_is_the_same_rule(native):
+    """mi355ntt_shard_range (the single-process multi-device driver's partition, csrc/shard.cpp) = ntt_cuda_amd.shard.shard_range
+    (the one-process-per-GPU form) on every case, and it rejects the same bad arguments (host only: no GPU)."""
+    from ntt_cuda_amd.shard import shard_range
+    rng = np.random.default_rng(11)
+    cases = [(8192, 4, 8), (1024, 4, 1), (10, 4, 3), (7, 3, 2), (0, 4, 2), (4, 4, 8), (33, 16, 2), (1023, 4, 8), (8192, 1, 8)]
+    cases += [(int(rng.integers(0, 20000)), int(rng.integers(1, 17)), int(rng.integers(1, 17))) for _ in range(200)]
+    for num, div, world in cases:
+        for r in range(world):
+            assert native.shard_range(num, div, r, world) == shard_range(num, div, r, world), (num, div, r, world)
+    for bad in [(8, 0, 0, 1), (8, 4, 1, 1), (8, 4, 0, 0)]:
+        with pytest.raises(native.NTTError):
+            native.shard_range(*bad)
+    # creation checks its arguments before it touches a device
+    import ctypes
+    h = ctypes.c_void_p()
+    assert native.lib().mi355ntt_shards_create(ctypes.byref(h), None, 2, 0) == native.EINVAL
+    assert native.lib().mi355ntt_shards_create(None, None, 0, 0) == native.EINVAL
+    assert native.lib().mi355ntt_shards_destroy(None) == native.OK
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -4,6 +4,8 @@
 usage: python tools/kernel_resources.py ntt-cuda_amd/csrc/kernels_fast_n15.hip [name-filter] [-- extra hipcc flags]
 Prints one line per kernel: demangled name, VGPRs, AGPRs, scratch bytes per lane, occupancy (waves per SIMD).
 Exit status 1 if any kernel whose name matches --require-no-scratch uses scratch.
+--asm-out PATH: the same compilation also leaves the gfx950 assembly at PATH (tools/valu_ceiling.py --asm reads it: one compile
+of the translation unit serves the scratch check and the VALU-ceiling drift check of the CPU test suite).
 """
 import re
 import subprocess
@@ -20,10 +22,15 @@ def main():
         k = args.index("--require-no-scratch")
         need = args[k + 1]
         del args[k:k + 2]
+    asm_out = None
+    if "--asm-out" in args:
+        k = args.index("--asm-out")
+        asm_out = args[k + 1]
+        del args[k:k + 2]
     src = args[0]
     flt = args[1] if len(args) > 1 else ""
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null",
-           "-Rpass-analysis=kernel-resource-usage"] + extra
+    out = ["-S", "--cuda-device-only", "-o", asm_out] if asm_out else ["-c", "-o", "/dev/null"]
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", src] + out + ["-Rpass-analysis=kernel-resource-usage"] + extra
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], {}
     for line in err.splitlines():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r03.json (read by bench.py).
+"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r04.json (read by bench.py).
 
 Compiles ntt-cuda_amd/csrc/kernels_fast_n15.hip to gfx950 assembly, sums the measured steady-state issue cost
 (tools/ubench_issue.hip, profiles/r02_ubench_issue_costs.txt) over the instructions of each kernel's polynomial loop
@@ -55,15 +55,13 @@ def loop_cost(lines, name_part):
     raise SystemExit("kernel %s not found" % name_part)
 
 
-def main():
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "n15.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "ntt-cuda_amd", "csrc"),
-                               "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
-                               os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip"), "-o", out], stderr=subprocess.DEVNULL)
-        lines = open(out).read().split('\n')
+KERNELS = (("k_forward15", "k_forward15ILi4ELb1ELi0"), ("k_inverse15", "k_inverse15ILi4ELb1"), ("k_polymul15", "k_polymul15ILi4ELb1"))
+PROFILE = os.path.join(ROOT, "profiles", "valu_ceiling_r04.json")
+
+
+def ceiling_from_asm(lines):
     res = {}
-    for k, sym in (("k_forward15", "k_forward15ILi4ELb1"), ("k_inverse15", "k_inverse15ILi4ELb1"), ("k_polymul15", "k_polymul15ILi4ELb1")):
+    for k, sym in KERNELS:
         cyc, nv, ni = loop_cost(lines, sym)
         per_poly = 4 * cyc                                    # 4 waves share a SIMD
         res[k] = {"valu_issue_cycles_per_wave": cyc, "valu_instructions_per_wave": nv, "loop_instructions": ni,
@@ -72,11 +70,50 @@ def main():
     res["source"] = ("tools/valu_ceiling.py: measured steady-state issue cycles per instruction (profiles/r02_ubench_issue_costs.txt) summed "
                      "over the polynomial loop of the shipped <HL 4, near-2^k> kernels, 4 waves per SIMD; transforms_per_s here at a nominal %d CUs x %.2f GHz "
                      "(bench.py re-prices cycles_per_polynomial_per_cu at the clock sampled inside its timed launches); "
-                     "the bare butterfly stream measures 11.1 M transforms/s (profiles/r02_ubench_butterfly_ceiling.txt)" % (CUS, CLOCK_HZ / 1e9))
-    path = os.path.join(ROOT, "profiles", "valu_ceiling_r03.json")
-    json.dump(res, open(path, "w"), indent=1)
+                     "the bare butterfly stream measures 11.5 M transforms/s sustained (profiles/r04_power_cap_and_overlap.txt).  "
+                     "tests/test_abi_host.py recomputes these figures from the shipped sources and fails on drift: regenerate with "
+                     "`python3 tools/valu_ceiling.py` in the same commit as any kernel change" % (CUS, CLOCK_HZ / 1e9))
+    return res
+
+
+def drift(res, ref):
+    """differences between a fresh computation and the committed profile (empty = in step)"""
+    bad = []
+    for k, _ in KERNELS:
+        for f in ("valu_instructions_per_wave", "loop_instructions"):
+            if res[k][f] != ref.get(k, {}).get(f):
+                bad.append("%s.%s: shipped sources %s, profile %s" % (k, f, res[k][f], ref.get(k, {}).get(f)))
+        a, b = res[k]["cycles_per_polynomial_per_cu"], ref.get(k, {}).get("cycles_per_polynomial_per_cu", 0.0)
+        if abs(a - b) > 1e-6 * max(a, b, 1.0):
+            bad.append("%s.cycles_per_polynomial_per_cu: shipped sources %.1f, profile %.1f" % (k, a, b))
+    return bad
+
+
+def main():
+    # usage: valu_ceiling.py [--asm FILE] [--check]   (--asm: an existing `hipcc -S --cuda-device-only` listing of kernels_fast_n15.hip;
+    # --check: compare with the committed profile instead of rewriting it, exit status 1 on drift)
+    args = sys.argv[1:]
+    asm = args[args.index("--asm") + 1] if "--asm" in args else None
+    if asm:
+        lines = open(asm).read().split('\n')
+    else:
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "n15.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "ntt-cuda_amd", "csrc"),
+                                   "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
+                                   os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip"), "-o", out], stderr=subprocess.DEVNULL)
+            lines = open(out).read().split('\n')
+    res = ceiling_from_asm(lines)
+    if "--check" in args:
+        bad = drift(res, json.load(open(PROFILE)))
+        for b in bad:
+            print(b)
+        print("valu ceiling profile %s" % ("DRIFTED: regenerate profiles/valu_ceiling_r04.json" if bad else "in step with the shipped sources"))
+        return 1 if bad else 0
+    json.dump(res, open(PROFILE, "w"), indent=1)
     print(json.dumps(res, indent=1))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
