@@ -79,9 +79,14 @@ int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt
  * what the reference's kernels print whenever its single-subtraction Barrett is exact for the modulus
  * (mi355ntt_barrett_is_exact: every modulus the reference ships, every q = 2^k - d with d^2 << 2^k).  For the rare
  * other primes (e.g. 68719230977, the second prime of decryption_test.cu) the reference occasionally returns q + r or,
- * one butterfly later, a wrong residue; a context holding such a prime therefore runs the literal stage-per-launch
+ * one butterfly later, a wrong residue; the polynomials of such a prime therefore run the literal stage-per-launch
  * kernels (same words as the reference, ~4x slower) unless MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES is passed to
- * mi355ntt_ctx_create_ex, which selects the exact kernels regardless.
+ * mi355ntt_ctx_create_ex, which selects the exact kernels regardless.  The routing is per prime: in a context that mixes both
+ * kinds (the reference's own decryption_test.cu set: primes 0 and 2 exact, prime 1 not) only the inexact primes' polynomials take
+ * the literal kernels -- each call gathers them into a buffer the context owns (allocated at creation: no allocation at call
+ * time), the throughput kernels transform the batch, the literal kernels the gathered rows, which are copied back; calls on
+ * different streams take turns on that buffer in stream order (an event, no host synchronisation).  n = 65536 contexts with an
+ * inexact prime stay literal as a whole.
  * ---------------------------------------------------------------------------------------------- */
 #define MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES 1u
 int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
@@ -89,7 +94,8 @@ int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
 int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
                            const mi355ntt_u64* q, const mi355ntt_u64* psi, int device, unsigned flags);
 int mi355ntt_ctx_destroy(mi355ntt_ctx* ctx);
-/* 1 when the transforms of this context run the literal (reference-arithmetic) kernels, see above */
+/* 0: every prime on the throughput kernels; 1: the whole context on the literal (reference-arithmetic) kernels; 2: per-prime
+ * routing, see above */
 int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_n(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_num_primes(const mi355ntt_ctx* ctx);

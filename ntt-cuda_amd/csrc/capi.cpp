@@ -46,8 +46,22 @@ struct mi355ntt_ctx {
     u64* d_psi = nullptr;        // [P][n]  psi^bitrev(i)      (reference format, demo.cu:188-196)
     u64* d_psiinv = nullptr;     // [P][n]  psi^-bitrev(i)
     FastTables fast;             // tables of the throughput kernels (kernels_fast.hip)
-    bool literal = false;        // some prime is not barrett_exact and the caller did not ask for exact results:
-                                 // transforms run the stage-per-launch kernels with the reference's arithmetic
+    bool literal = false;        // every prime is Barrett-inexact (or n = 2^16 with one that is) and the caller did not ask for exact
+                                 // results: transforms run the stage-per-launch kernels with the reference's arithmetic
+    // Per-prime routing (round 4).  inexact_mask: bit i = prime i is not barrett_exact (and no MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES).
+    // A context with SOME such primes is `mixed`: the polynomials of those primes run the literal kernels, everything else the
+    // throughput kernels -- the reference's words either way.  The literal share of a call goes through a gather buffer
+    // (rows_per_prime rows per inexact prime, allocated with the context); calls take turns on it in stream order (event `last`).
+    unsigned inexact_mask = 0;
+    bool mixed = false;
+    struct Mixed {
+        u64* d = nullptr;
+        unsigned rows_per_prime = 0;
+        hipEvent_t last = nullptr;
+        bool used = false;
+        std::mutex m;
+    };
+    mutable Mixed mix;
     // n = 2^16 (beyond the reference's dispatch): stage 1 splits the transform into two independent half-size ones whose
     // stage `L` reads table entries [2L + h L, 2L + (h + 1) L) -- an ordinary 2^15 transform on a derived table.  `fast`
     // then holds 2 P "virtual primes" (2 i + h) for n/2, polynomial y's half h is virtual polynomial 2 y + h.
@@ -66,8 +80,64 @@ static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
     return r;
 }
 
+// residues r < division whose prime (base + r) is Barrett-inexact in a mixed context
+static unsigned inexact_residues(const mi355ntt_ctx* c, unsigned division, unsigned base)
+{
+    return c->mixed ? (c->inexact_mask >> base) & ((division >= 32 ? 0u : (1u << division)) - 1u) : 0u;
+}
+
+// Mixed context, a call that touches both kinds of primes: the batch is walked in chunks of rows_per_prime groups of `division`
+// polynomials.  Per chunk: the rows of the inexact primes are gathered into the context's buffer (strided device-to-device copies),
+// the throughput kernels transform the whole chunk in place (their result for the gathered rows is discarded), the literal kernels
+// transform the gathered rows with the reference's arithmetic, and those rows are copied back over the chunk.  Everything is
+// enqueued on `s`; another stream's mixed call on the same context waits for this one's last event before it touches the buffer.
+static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsigned num, unsigned division, unsigned base, unsigned sub, hipStream_t s)
+{
+    mi355ntt_ctx::Mixed& mx = c->mix;
+    std::lock_guard<std::mutex> lock(mx.m);
+    hipError_t e;
+    if (mx.used && (e = hipStreamWaitEvent(s, mx.last, 0)) != hipSuccess) return e;
+    const unsigned G = mx.rows_per_prime;
+    const size_t row = (size_t)c->n * sizeof(u64);
+    const u64* tabs = inverse ? c->d_psiinv : c->d_psi;
+    for (unsigned y0 = 0; y0 < num; y0 += G * division) {
+        const unsigned cnt = num - y0 < G * division ? num - y0 : G * division;
+        u64* chunk = d_a + (size_t)y0 * c->n;
+        unsigned slot = 0;
+        for (unsigned r = 0; r < division; r++) {
+            if (!((sub >> r) & 1u)) continue;
+            const unsigned rows = cnt > r ? (cnt - r + division - 1) / division : 0;
+            if (rows && (e = hipMemcpy2DAsync(mx.d + (size_t)slot * G * c->n, row, chunk + (size_t)r * c->n, division * row, row, rows,
+                                              hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+            slot++;
+        }
+        e = inverse ? fast_inverse_batch(c->fast, chunk, cnt, division, base, s) : fast_forward_batch(c->fast, chunk, cnt, division, base, s);
+        if (e != hipSuccess) return e;
+        slot = 0;
+        for (unsigned r = 0; r < division; r++) {
+            if (!((sub >> r) & 1u)) continue;
+            const unsigned rows = cnt > r ? (cnt - r + division - 1) / division : 0;
+            u64* buf = mx.d + (size_t)slot * G * c->n;
+            slot++;
+            if (!rows) continue;
+            const ModSet m1 = mods_from(c, base + r, 1);
+            e = inverse ? compat_inverse_batch(buf, c->n, tabs + (size_t)(base + r) * c->n, rows, 1, m1, s)
+                        : compat_forward_batch(buf, c->n, tabs + (size_t)(base + r) * c->n, rows, 1, m1, s);
+            if (e != hipSuccess) return e;
+            if ((e = hipMemcpy2DAsync(chunk + (size_t)r * c->n, division * row, buf, row, row, rows, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+        }
+    }
+    mx.used = (hipEventRecord(mx.last, s) == hipSuccess);
+    if (!mx.used) (void)hipStreamSynchronize(s);
+    return hipSuccess;
+}
+
 static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
+    if (const unsigned sub = inexact_residues(c, division, base)) {
+        if (sub == (1u << division) - 1u) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+        return run_mixed(c, false, d_a, num, division, base, sub, s);
+    }
     if (c->literal) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides in the loads of the lower halves' launch (1.5 passes over memory instead of 2)
@@ -81,6 +151,10 @@ static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, uns
 
 static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
+    if (const unsigned sub = inexact_residues(c, division, base)) {
+        if (sub == (1u << division) - 1u) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+        return run_mixed(c, true, d_a, num, division, base, sub, s);
+    }
     if (c->literal) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides behind the lower halves' last round (1.5 passes over memory instead of 2)
@@ -170,7 +244,7 @@ int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes, con
     return mi355ntt_ctx_create_ex(out, n, num_primes, q, psi, device, 0);
 }
 
-int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* c) { return (c && c->literal) ? 1 : 0; }
+int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* c) { return !c ? 0 : c->literal ? 1 : c->mixed ? 2 : 0; }
 
 int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, const mi355ntt_u64* q, const mi355ntt_u64* psi,
                            int device, unsigned flags)
@@ -197,7 +271,13 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
         c->mods.q[i] = c->prime[i].q;
         c->mods.mu[i] = c->prime[i].mu;
         c->mods.k[i] = c->prime[i].k;
-        if (!c->prime[i].barrett_exact && !(flags & MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES)) c->literal = true;
+        if (!c->prime[i].barrett_exact && !(flags & MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES)) c->inexact_mask |= 1u << i;
+    }
+    // every prime inexact -> the whole context runs the literal kernels; some -> per-prime routing (n = 2^16: its split path has no
+    // mixed form, the whole context stays literal as before)
+    if (c->inexact_mask) {
+        if (c->inexact_mask == (num_primes >= 32 ? ~0u : (1u << num_primes) - 1u) || n == 65536) c->literal = true;
+        else c->mixed = true;
     }
 
     auto fail = [&](int code) {
@@ -249,6 +329,15 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
     } else {
         e = fast_tables_create(&c->fast, n, num_primes, c->prime, hp.data(), hi.data(), c->d_psi, c->d_psiinv);
     }
+    if (e == hipSuccess && c->mixed) {
+        // the gather buffer of the literal share: at most 32 MiB, 16 .. 256 groups per chunk
+        const unsigned bad = (unsigned)__builtin_popcount(c->inexact_mask);
+        size_t rows = ((size_t)32 << 20) / ((size_t)n * sizeof(u64) * bad);
+        rows = rows < 16 ? 16 : rows > 256 ? 256 : rows;
+        c->mix.rows_per_prime = (unsigned)rows;
+        e = hipMalloc((void**)&c->mix.d, rows * bad * n * sizeof(u64));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->mix.last, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return fail(e == hipErrorOutOfMemory ? MI355NTT_ENOMEM : MI355NTT_EHIP);
@@ -263,6 +352,8 @@ int mi355ntt_ctx_destroy(mi355ntt_ctx* c)
     DeviceScope scope(c->device);
     if (c->d_psi) (void)hipFree(c->d_psi);
     if (c->d_psiinv) (void)hipFree(c->d_psiinv);
+    if (c->mix.d) (void)hipFree(c->mix.d);
+    if (c->mix.last) (void)hipEventDestroy(c->mix.last);
     fast_tables_destroy(&c->fast);
     delete c;
     return MI355NTT_OK;
@@ -376,7 +467,7 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355
         HIP_TRY(fast_inverse_split16(c->fast, d_a, num, division, 0, (hipStream_t)s, d_bhat));
         return MI355NTT_OK;
     }
-    if (c->literal || c->split16) {   // the reference's own sequence (bfv_encryption.cuh:268-271), three calls
+    if (c->literal || c->mixed || c->split16) {   // the reference's own sequence (bfv_encryption.cuh:268-271), three calls
         HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
         HIP_TRY(compat_pointwise(d_a, d_a, d_bhat, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s));
         HIP_TRY(run_inverse(c, d_a, num, division, 0, (hipStream_t)s));
@@ -394,7 +485,7 @@ int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* c, mi355ntt_u64* d_a, cons
     if (!d_bhat || (group && group % division) || group >= (1u << 23)) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
     ON_CTX_DEVICE(c);
-    if (!c->literal && !c->split16) {
+    if (!c->literal && !c->mixed && !c->split16) {
         const hipError_t e = fast_polymul_batch(c->fast, d_a, d_bhat, num, division, (hipStream_t)s, true, group);
         if (e == hipSuccess) return MI355NTT_OK;
         if (e != hipErrorNotSupported) HIP_TRY(e);

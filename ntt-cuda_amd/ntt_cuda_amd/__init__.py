@@ -305,6 +305,12 @@ class NTTContext:
     def uses_literal_kernels(self):
         return bool(lib().mi355ntt_ctx_uses_literal_kernels(self._h))
 
+    @property
+    def literal_routing(self):
+        """0: throughput kernels for every prime; 1: literal kernels for every prime; 2: per prime -- the polynomials of the
+        Barrett-inexact primes run the literal kernels, all others the throughput kernels (mi355ntt_ctx_uses_literal_kernels)"""
+        return int(lib().mi355ntt_ctx_uses_literal_kernels(self._h))
+
     def prime(self, i):
         q, mu, psi, psiinv = u64(), u64(), u64(), u64()
         bits = ctypes.c_uint()

@@ -115,3 +115,72 @@ def test_rccl_is_initialised_and_used_once_world_size_1(native, gpu):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + _NCCL_CHILD], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "NCCL-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_per_prime_literal_routing_on_the_kat1_moduli(native, oracle, gpu):
+    """decryption_test.cu's own primes: 0 and 2 are Barrett-exact, prime 1 (68719230977) is not.  The context routes per prime
+    (mi355ntt_ctx_uses_literal_kernels == 2): polynomials of prime 1 through the literal kernels, the others through the throughput
+    kernels -- and every word is the oracle's (the reference's, including its non-canonical outputs on prime 1), for batches that
+    span several gather chunks, ragged tails, sub-ranges of the primes, two streams at once, and the fused-product entry points."""
+    import torch
+    from test_barrett_exactness import KAT_Q, KAT_PSI
+    n = 4096
+    ctx = native.NTTContext(n, KAT_Q, KAT_PSI)
+    assert ctx.literal_routing == 2 and ctx.uses_literal_kernels
+    assert [native.barrett_is_exact(q) for q in KAT_Q] == [True, False, True]
+    prm = oracle.Params(n, KAT_Q, KAT_PSI)
+    for num in (3, 1000, 1537):                       # 256 groups of 3 per chunk: 1 chunk, 2 chunks (ragged), 3 chunks (ragged)
+        # ternary-like inputs hit the inexact case often (operand q - 1): oracle.bfv_sample's ternary rows, tiled, plus uniform rows
+        tern = oracle.bfv_sample(KAT_Q, n, 7)["ternary"]
+        a = oracle.synth_batch(n, num, KAT_Q, 100 + num).reshape(num, n)
+        for y in range(0, num, 5):
+            a[y] = tern[y % 3]
+        want_f = oracle.forward_batch(a.copy(), prm).reshape(num, n)
+        if num >= 1000:
+            assert (want_f[1::3] >= KAT_Q[1]).any()      # the reference's non-canonical words are part of the expectation
+        d = native.to_device(a)
+        ctx.forward_batch(d, num)
+        torch.cuda.synchronize()
+        assert np.array_equal(native.to_host(d).reshape(num, n), want_f), ("forward", num)
+        ctx.inverse_batch(d, num)
+        assert np.array_equal(native.to_host(d).reshape(num, n), oracle.inverse_batch(want_f.copy(), prm).reshape(num, n)), ("inverse", num)
+    # two streams at once on the same context: the gather buffer changes hands in stream order
+    num = 900
+    a = oracle.synth_batch(n, num, KAT_Q, 55).reshape(num, n)
+    b = oracle.synth_batch(n, num, KAT_Q, 56).reshape(num, n)
+    def chain(x):          # the same seven transforms in the reference's arithmetic (on prime 1 inverse(forward(x)) need not be x)
+        w = x.copy()
+        for _ in range(3):
+            w = oracle.inverse_batch(oracle.forward_batch(w, prm), prm)
+        return oracle.forward_batch(w, prm).reshape(num, n)
+
+    want_a, want_b = chain(a), chain(b)
+    da, db = native.to_device(a), native.to_device(b)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        ctx.forward_batch(da, num, stream=s1); ctx.forward_batch(db, num, stream=s2)
+        ctx.inverse_batch(da, num, stream=s1); ctx.inverse_batch(db, num, stream=s2)
+    ctx.forward_batch(da, num, stream=s1); ctx.forward_batch(db, num, stream=s2)
+    torch.cuda.synchronize()
+    assert np.array_equal(native.to_host(da).reshape(num, n), want_a) and np.array_equal(native.to_host(db).reshape(num, n), want_b)
+    # single-polynomial entry points pick the kernel class of their prime; a division that covers only exact primes runs fast kernels
+    for i in range(3):
+        x = oracle.synth_batch(n, 1, [KAT_Q[i]], 9 + i)[0]
+        dx = native.to_device(x)
+        ctx.forward(dx, i)
+        assert np.array_equal(native.to_host(dx), oracle.forward(x, prm, i)), i
+    one = oracle.synth_batch(n, 40, KAT_Q[:1], 77).reshape(40, n)
+    d1 = native.to_device(one)
+    ctx.forward_batch(d1, 40, division=1)
+    prm0 = oracle.Params(n, KAT_Q[:1], KAT_PSI[:1])
+    assert np.array_equal(native.to_host(d1).reshape(40, n), oracle.forward_batch(one.copy(), prm0).reshape(40, n))
+    # fused product = the reference's three-step sequence on every prime
+    num = 301
+    a = oracle.synth_batch(n, num, KAT_Q, 61).reshape(num, n)
+    bh = oracle.synth_batch(n, num, KAT_Q, 62).reshape(num, n)
+    da = native.to_device(a)
+    ctx.polymul_batch(da, native.to_device(bh), num)
+    want = oracle.inverse_batch(oracle.pointwise_batch(oracle.forward_batch(a.copy(), prm), bh, prm), prm)
+    assert np.array_equal(native.to_host(da).reshape(-1), want.reshape(-1))
+    ctx.close()
