@@ -267,6 +267,17 @@ int mi355ntt_barrett_raw(mi355ntt_u64* d_c, const mi355ntt_u64* d_a, const mi355
 int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_u64 q, mi355ntt_u64 mu,
                              int bit_length, mi355ntt_stream stream);                             /* barrett_int :100 */
 
+/* The stand-alone element-wise host wrappers of poly_arithmetic.cuh:312-352, same argument order (one polynomial of n words, in
+ * place in d_a; the BFV drivers above carry the same arithmetic fused into their own kernels).  The reference's words, quirks
+ * included: poly_add / poly_add_integer reduce with `>` (a sum equal to q stays q, :144-166); poly_sub (:168-179) only adds q where
+ * a[i] < b[i] and never subtracts b -- mirrored literally, it is what the reference computes; poly_negate maps 0 to 0 (:334-338);
+ * poly_mul_int_t masks the low 64 bits of a[i] b with t - 1 held in a 32-bit register (:128-142).  Pointers 16-byte aligned. */
+int mi355ntt_poly_add_raw(mi355ntt_u64* d_a, const mi355ntt_u64* d_b, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q);          /* poly_add_device :312 */
+int mi355ntt_poly_mul_int_t_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_stream stream, mi355ntt_u64 t);             /* poly_mul_int_t :322 */
+int mi355ntt_poly_sub_raw(mi355ntt_u64* d_a, const mi355ntt_u64* d_b, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q);          /* poly_sub_device :327 */
+int mi355ntt_poly_negate_raw(mi355ntt_u64* d_a, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q);                                /* poly_negate_device :340 */
+int mi355ntt_poly_add_integer_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q);           /* poly_add_integer_device(_default) :345-352 */
+
 /* ------------------------------------------------------------------------------------------------
  * The reference's 30-bit path (old/ntt_30bit.cuh): 32-bit words, q < 2^30, the caller's mu
  * (floor(2^(2 bits) / q), old/30bit_ntt_test.cu:47-48) and 32-bit psi tables.  Same argument lists as the reference's

@@ -1,4 +1,5 @@
-// poly_arithmetic.hpp -- C++ host mirror of the pointwise-product part of BFV_Scheme/poly_arithmetic.cuh.
+// poly_arithmetic.hpp -- C++ host mirror of the pointwise-product part and of the element-wise host wrappers (:312-352) of
+// BFV_Scheme/poly_arithmetic.cuh.
 //
 // The reference exposes `barrett*` as __global__ kernels that callers launch themselves with
 // <<<n/256[, num], 256, 0, stream>>> (60bit_ntt_test.cu:76, bfv_encryption.cuh:269-270).  Here each is a host
@@ -37,6 +38,40 @@ inline int poly_mul_int(unsigned long long* device_a, const unsigned long long b
                         unsigned long long q, unsigned long long mu, int bit_length)
 {
     return mi355ntt_barrett_int_raw(device_a, b, n, q, mu, bit_length, stream);
+}
+
+// poly_add_device   poly_arithmetic.cuh:312  (a[i] = a[i] + b[i], minus q where the sum is > q)
+inline int poly_add_device(unsigned long long* device_a, const unsigned long long* device_b, unsigned n, hipStream_t& stream, unsigned long long q)
+{
+    return mi355ntt_poly_add_raw(device_a, device_b, n, stream, q);
+}
+
+// poly_mul_int_t   poly_arithmetic.cuh:322  (mod_t: low 64 bits of a[i] b, masked with the 32-bit t - 1)
+inline int poly_mul_int_t(unsigned long long* device_a, const unsigned long long b, unsigned n, hipStream_t& stream, unsigned long long t)
+{
+    return mi355ntt_poly_mul_int_t_raw(device_a, b, n, stream, t);
+}
+
+// poly_sub_device   poly_arithmetic.cuh:327  (the reference's poly_sub adds q where a[i] < b[i] and never subtracts b: mirrored)
+inline int poly_sub_device(unsigned long long* device_a, const unsigned long long* device_b, unsigned n, hipStream_t& stream, unsigned long long q)
+{
+    return mi355ntt_poly_sub_raw(device_a, device_b, n, stream, q);
+}
+
+// poly_negate_device   poly_arithmetic.cuh:340
+inline int poly_negate_device(unsigned long long* device_a, unsigned n, hipStream_t& stream, unsigned long long q)
+{
+    return mi355ntt_poly_negate_raw(device_a, n, stream, q);
+}
+
+// poly_add_integer_device / poly_add_integer_device_default   poly_arithmetic.cuh:345-352
+inline int poly_add_integer_device(unsigned long long* device_a, unsigned long long b, unsigned n, hipStream_t& stream, unsigned long long q)
+{
+    return mi355ntt_poly_add_integer_raw(device_a, b, n, stream, q);
+}
+inline int poly_add_integer_device_default(unsigned long long* device_a, unsigned long long b, unsigned n, unsigned long long q)
+{
+    return mi355ntt_poly_add_integer_raw(device_a, b, n, nullptr, q);
 }
 
 // half_poly_mul_device   poly_arithmetic.cuh:303-310: a = INTT(NTT(a) (.) b), b already in the NTT domain

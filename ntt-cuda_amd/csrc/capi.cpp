@@ -537,6 +537,36 @@ int mi355ntt_ctx_probed_clock_mhz(const mi355ntt_ctx* c, double* mhz)
     return MI355NTT_OK;
 }
 
+/* ---------------- the element-wise wrappers of poly_arithmetic.cuh:312-352 ---------------- */
+static int elementwise(int op, mi355ntt_u64* d_a, const mi355ntt_u64* d_b, bool need_b, mi355ntt_u64 scalar, mi355ntt_u64 q, unsigned n, mi355ntt_stream s)
+{
+    if (!d_a || (need_b && !d_b) || q == 0) return MI355NTT_EINVAL;
+    if (((uintptr_t)d_a & 15u) || (need_b && ((uintptr_t)d_b & 15u))) return MI355NTT_EINVAL;      /* 16-byte accesses */
+    (void)hipGetLastError();
+    HIP_TRY(compat_elementwise(op, d_a, d_b, scalar, q, n, (hipStream_t)s));
+    return MI355NTT_OK;
+}
+int mi355ntt_poly_add_raw(mi355ntt_u64* d_a, const mi355ntt_u64* d_b, unsigned n, mi355ntt_stream s, mi355ntt_u64 q)
+{
+    return elementwise(kEwAdd, d_a, d_b, true, 0, q, n, s);
+}
+int mi355ntt_poly_sub_raw(mi355ntt_u64* d_a, const mi355ntt_u64* d_b, unsigned n, mi355ntt_stream s, mi355ntt_u64 q)
+{
+    return elementwise(kEwSub, d_a, d_b, true, 0, q, n, s);
+}
+int mi355ntt_poly_negate_raw(mi355ntt_u64* d_a, unsigned n, mi355ntt_stream s, mi355ntt_u64 q)
+{
+    return elementwise(kEwNegate, d_a, nullptr, false, 0, q, n, s);
+}
+int mi355ntt_poly_add_integer_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_stream s, mi355ntt_u64 q)
+{
+    return elementwise(kEwAddInteger, d_a, nullptr, false, b, q, n, s);
+}
+int mi355ntt_poly_mul_int_t_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_stream s, mi355ntt_u64 t)
+{
+    return elementwise(kEwMulIntT, d_a, nullptr, false, b, t, n, s);
+}
+
 /* ---------------- raw-parameter entry points ---------------- */
 static int fill_modset(ModSet* m, unsigned division, const mi355ntt_u64* q, const mi355ntt_u64* mu, const unsigned* bits)
 {

@@ -56,6 +56,9 @@ hipError_t compat_gs_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned len
 hipError_t compat_pointwise(u64* d_c, const u64* d_a, const u64* d_b, unsigned n, unsigned num, unsigned division,
                             const ModSet& m, hipStream_t s, bool shared_b = false, unsigned group = 0);
 hipError_t compat_pointwise_scalar(u64* d_a, u64 b, unsigned n, u64 q, u64 mu, unsigned k, hipStream_t s);
+// the element-wise wrappers of poly_arithmetic.cuh:312-352, reference arithmetic word for word (kernels_compat.hip): d_a[i] <- op(d_a[i], d_b[i] or scalar)
+enum { kEwAdd = 0, kEwAddInteger = 1, kEwSub = 2, kEwNegate = 3, kEwMulIntT = 4 };
+hipError_t compat_elementwise(int op, u64* d_a, const u64* d_b, u64 scalar, u64 q_or_t, size_t count, hipStream_t s);
 // a[y][i] = splitmix64(seed_base + y)_i mod q[y % division]: the synthetic inputs of SURVEY.md 4.2 / 8d, generated on the device
 hipError_t compat_synth_splitmix(u64* d_a, unsigned n, unsigned num, unsigned division, const ModSet& m, u64 seed_base, hipStream_t s);
 // *d_flag |= 1 when two sets of `count` reference-format tables differ in an entry the transforms read (index != 0)

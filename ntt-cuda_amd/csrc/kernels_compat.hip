@@ -357,4 +357,62 @@ hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsig
     return hipGetLastError();
 }
 
+
+// ---- the stand-alone element-wise wrappers of poly_arithmetic.cuh:312-352 -----------------------------------------------------
+// poly_add (:144-154: `>`, not `>=` -- a sum equal to q stays q), poly_add_integer (:156-166, same comparison), poly_sub (:168-179:
+// adds q where a < b and NEVER subtracts b -- mirrored literally), poly_negate (:334-338), mod_t (:128-142:
+// the low 64 bits of a b, masked with t - 1 held in a 32-bit register).  One streaming kernel, 16 bytes per lane, grid-stride.
+namespace {
+template <int OP>
+__global__ void __launch_bounds__(256) k_elementwise(u64* __restrict__ a, const u64* __restrict__ b, u64 scalar, u64 q, size_t count)
+{
+    auto f = [&](u64 x, u64 y) -> u64 {
+        if constexpr (OP == kEwAdd || OP == kEwAddInteger) {
+            u64 r = x + y;
+            if (r > q) r -= q;
+            return r;
+        } else if constexpr (OP == kEwSub) {
+            return x < y ? x + q : x;
+        } else if constexpr (OP == kEwNegate) {
+            const u64 r = q - x;
+            return r * (u64)(r != q);
+        } else {
+            return (x * y) & (u64)(unsigned)(q - 1);                // (q carries t: `register unsigned mask = t - 1`)
+        }
+    };
+    constexpr bool VEC_B = (OP == kEwAdd || OP == kEwSub);
+    const size_t pairs = count / 2, stride = (size_t)gridDim.x * 256;
+    ulonglong2* a2 = reinterpret_cast<ulonglong2*>(a);
+    const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride) {
+        ulonglong2 x = a2[i];
+        ulonglong2 y;
+        if constexpr (VEC_B) y = b2[i];
+        else y = make_ulonglong2(scalar, scalar);
+        x.x = f(x.x, y.x);
+        x.y = f(x.y, y.y);
+        a2[i] = x;
+    }
+    if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) a[count - 1] = f(a[count - 1], VEC_B ? b[count - 1] : scalar);
+}
+}  // namespace
+
+hipError_t compat_elementwise(int op, u64* d_a, const u64* d_b, u64 scalar, u64 q, size_t count, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    size_t blocks = (count / 2 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    const unsigned g = (unsigned)blocks;
+    switch (op) {
+    case kEwAdd: k_elementwise<kEwAdd><<<g, 256, 0, s>>>(d_a, d_b, 0, q, count); break;
+    case kEwAddInteger: k_elementwise<kEwAddInteger><<<g, 256, 0, s>>>(d_a, nullptr, scalar, q, count); break;
+    case kEwSub: k_elementwise<kEwSub><<<g, 256, 0, s>>>(d_a, d_b, 0, q, count); break;
+    case kEwNegate: k_elementwise<kEwNegate><<<g, 256, 0, s>>>(d_a, nullptr, 0, q, count); break;
+    case kEwMulIntT: k_elementwise<kEwMulIntT><<<g, 256, 0, s>>>(d_a, nullptr, scalar, q, count); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 }  // namespace mi355ntt

@@ -907,8 +907,12 @@ inline bool use_latency_path(unsigned num, bool fused)
     return LOGN == 15 && num > 256u && num <= (fused ? 384u : 352u);
 }
 
-// the context's kernel class (FastTables::hl: bits 0-3 headroom class, bit 4 every prime near 2^k) as compile-time arguments
-template <class F>
+// the context's kernel class (FastTables::hl: bits 0-3 headroom class, bit 4 every prime near 2^k) as compile-time arguments.
+// Classes: 6 (<= 58-bit moduli: no intermediate reduction), 4 (59/60-bit: one every 2-3 stages), 3 (61-bit near-2^k, round 4: 8 q < 2^64, so the
+// lazy three-product quotient estimate with values in [0, 4q) still fits -- one partial reduction per stage, but no 64 x 64 high
+// product; the reference's decryption modulus gamma is 61-bit, demo.cu:93) and 2 (62-bit: exact quotients, values in [0, 2q)).
+// WITH3 = false (the n = 2^16 split / pair kernels): 61-bit moduli stay in class 2 there.
+template <bool WITH3 = true, class F>
 inline void dispatch_class(int hl, F&& f)
 {
     const bool near = (hl & 16) != 0;
@@ -917,10 +921,13 @@ inline void dispatch_class(int hl, F&& f)
     if (near) {
         if (h >= 6) f(integral_constant<int, 6>{}, integral_constant<bool, true>{});
         else if (h >= 4) f(integral_constant<int, 4>{}, integral_constant<bool, true>{});
+        else if (WITH3 && h == 3) f(integral_constant<int, WITH3 ? 3 : 2>{}, integral_constant<bool, true>{});
         else f(integral_constant<int, 2>{}, integral_constant<bool, true>{});
     } else {
         if (h >= 6) f(integral_constant<int, 6>{}, integral_constant<bool, false>{});
         else if (h >= 4) f(integral_constant<int, 4>{}, integral_constant<bool, false>{});
+        // (general 61-bit primes stay in class 2: their per-stage partial reduction is the 7-instruction form, and with it the class-3
+        // inverse and fused kernels need 36-52 bytes of scratch per lane at n = 2^13 .. 2^15 -- measured with the compiler's remarks)
         else f(integral_constant<int, 2>{}, integral_constant<bool, false>{});
     }
 }

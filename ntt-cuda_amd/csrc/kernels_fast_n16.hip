@@ -25,7 +25,7 @@ static hipError_t launch_fwd_split16(int hl, u64* d_a, const TwPair* tw, const P
 {
 #ifndef MI355NTT_ONLY_HL4N
     dim3 g(persistent_grid<15>(num)), b(1024);
-    dispatch_class(hl, [&](auto hc, auto nc) {
+    dispatch_class<false>(hl, [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
         k_forward15<H, NR, 1><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -39,7 +39,7 @@ static hipError_t launch_inv_split16(int hl, u64* d_a, const u64* d_bhat, const 
 {
 #ifndef MI355NTT_ONLY_HL4N
     dim3 g(persistent_grid<15>(num)), b(1024);
-    dispatch_class(hl, [&](auto hc, auto nc) {
+    dispatch_class<false>(hl, [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
         if (d_bhat) k_inverse15_split<H, NR, true><<<g, b, 0, s>>>(d_a, d_bhat, tw, pr, division, base, num);
@@ -58,7 +58,7 @@ hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* 
     if (2 * pairs > kPairFlagWords) return hipErrorInvalidValue;
     dim3 g(2 * pairs), b(1024);
     bool launched = true;
-    dispatch_class(hl, [&](auto hc, auto nc) {
+    dispatch_class<false>(hl, [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
         // (the 61/62-bit classes -- exact quotients, a reduction in every stage -- fit 128 VGPRs in this form only with spills and

@@ -446,6 +446,13 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // Inline asm: callers fence with wave_lds_fence() / a barrier before the words are read (the compiler's own waitcnt
 // insertion does not see these stores).
 template <int OFF8>
+__device__ __forceinline__ void lds_write2_u64(__attribute__((address_space(3))) u64* addr, u64 a, u64 b)
+{
+    static_assert(OFF8 >= 0 && OFF8 + 1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
+    const u32 la = (u32)reinterpret_cast<uintptr_t>(addr);
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(la), "v"(a), "v"(b), "n"(OFF8), "n"(OFF8 + 1) : "memory");
+}
+template <int OFF8>
 __device__ __forceinline__ void lds_write2_u64(u64* addr, u64 a, u64 b)
 {
     static_assert(OFF8 >= 0 && OFF8 + 1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
@@ -476,8 +483,14 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
     asm volatile("" : "+v"(ws0), "+v"(rs0));
     unsigned ws1 = ws0 + SEG, ws2 = ws0 + 2 * SEG, rs1 = rs0 + SEG, rs2 = rs0 + 2 * SEG;
     asm volatile("" : "+v"(ws1), "+v"(ws2), "+v"(rs1), "+v"(rs2));
-    u64* const wb[3] = {lds + ws0, lds + ws1, lds + ws2};
-    const u64* const rb[3] = {lds + rs0, lds + rs1, lds + rs2};
+    // (bases as LDS-address-space pointers: formed as generic pointers they drag the aperture's high word along in a VGPR pair --
+    // the last 12 bytes of scratch of k_inverse<13|14, 4, false>)
+    typedef __attribute__((address_space(3))) u64 LdsWord;
+    typedef u64 v2u64 __attribute__((ext_vector_type(2)));       // (a builtin vector: the HIP vector classes have no LDS-qualified members)
+    typedef __attribute__((address_space(3))) v2u64 LdsPair;
+    LdsWord* const lds3 = (LdsWord*)lds;
+    LdsWord* const wb[3] = {lds3 + ws0, lds3 + ws1, lds3 + ws2};
+    const LdsWord* const rb[3] = {lds3 + rs0, lds3 + rs1, lds3 + rs2};
     u64 nv[32];
     static_for<PH>([&](auto phc) {
         constexpr unsigned ph = decltype(phc)::value;
@@ -490,7 +503,7 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
                     if constexpr (BO == 0 && (off % SEG) + 1 < 256)
                         lds_write2_u64<off % SEG>(wb[off / SEG], v[r], v[r + 1]);       // (pair store without a register tuple)
                     else if constexpr (BO == 0)
-                        *reinterpret_cast<ulonglong2*>(wb[off / SEG] + off % SEG) = make_ulonglong2(v[r], v[r + 1]);
+                        *reinterpret_cast<LdsPair*>(wb[off / SEG] + off % SEG) = v2u64{v[r], v[r + 1]};
                     else
                         wb[off / SEG][off % SEG] = v[r];
                 }
@@ -503,7 +516,7 @@ __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
             if constexpr (!G::TWO_PHASE || (unsigned)(r >> 4) == ph) {
                 constexpr unsigned off = slot_of(drop_bit<PB>((unsigned)r << BN));
                 if constexpr (BN == 0) {
-                    const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(rb[off / SEG] + off % SEG);
+                    const v2u64 pr = *reinterpret_cast<const LdsPair*>(rb[off / SEG] + off % SEG);
                     nv[r] = pr.x;
                     nv[r + 1] = pr.y;
                 } else {

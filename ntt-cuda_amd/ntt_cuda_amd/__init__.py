@@ -97,6 +97,11 @@ _SIGNATURES = {
     "mi355ntt_forward_batch_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, vp]),
     "mi355ntt_inverse_batch_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, vp]),
     "mi355ntt_barrett_raw": (ctypes.c_int, [vp, vp, vp, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, u64p, u64p, u32p, vp]),
+    "mi355ntt_poly_add_raw": (ctypes.c_int, [vp, vp, ctypes.c_uint, vp, u64]),
+    "mi355ntt_poly_sub_raw": (ctypes.c_int, [vp, vp, ctypes.c_uint, vp, u64]),
+    "mi355ntt_poly_negate_raw": (ctypes.c_int, [vp, ctypes.c_uint, vp, u64]),
+    "mi355ntt_poly_add_integer_raw": (ctypes.c_int, [vp, u64, ctypes.c_uint, vp, u64]),
+    "mi355ntt_poly_mul_int_t_raw": (ctypes.c_int, [vp, u64, ctypes.c_uint, vp, u64]),
     "mi355ntt_barrett_int_raw": (ctypes.c_int, [vp, u64, ctypes.c_uint, u64, u64, ctypes.c_int, vp]),
 }
 
@@ -482,6 +487,28 @@ class Moduli:
 
     def args(self):
         return self.q.ctypes.data_as(u64p), self.mu.ctypes.data_as(u64p), self.bits.ctypes.data_as(u32p)
+
+
+# the element-wise host wrappers of poly_arithmetic.cuh:312-352 (same names and argument order)
+def poly_add_device(device_a, device_b, n, stream, q):
+    _check(lib().mi355ntt_poly_add_raw(_ptr_n(device_a, n), _ptr_n(device_b, n), int(n), _stream(stream), int(q)), "poly_add_device")
+
+
+def poly_mul_int_t(device_a, b, n, stream, t):
+    _check(lib().mi355ntt_poly_mul_int_t_raw(_ptr_n(device_a, n), int(b), int(n), _stream(stream), int(t)), "poly_mul_int_t")
+
+
+def poly_sub_device(device_a, device_b, n, stream, q):
+    """the reference's poly_sub (poly_arithmetic.cuh:168-179) adds q where a[i] < b[i] and never subtracts b: mirrored literally"""
+    _check(lib().mi355ntt_poly_sub_raw(_ptr_n(device_a, n), _ptr_n(device_b, n), int(n), _stream(stream), int(q)), "poly_sub_device")
+
+
+def poly_negate_device(device_a, n, stream, q):
+    _check(lib().mi355ntt_poly_negate_raw(_ptr_n(device_a, n), int(n), _stream(stream), int(q)), "poly_negate_device")
+
+
+def poly_add_integer_device(device_a, b, n, stream, q):
+    _check(lib().mi355ntt_poly_add_integer_raw(_ptr_n(device_a, n), int(b), int(n), _stream(stream), int(q)), "poly_add_integer_device")
 
 
 def raw_cache_clear():

@@ -181,6 +181,37 @@ def pointwise_scalar(a, b, prm, idx=0):
     return a
 
 
+# ---- the stand-alone element-wise kernels of poly_arithmetic.cuh (numpy restatements; uint64 arithmetic wraps as the reference's) ----
+def poly_add(a, b, q):
+    """poly_add, poly_arithmetic.cuh:144-154: ra = a[i] + b[i]; if (ra > q) ra -= q  (note `>`: a sum equal to q stays q)"""
+    r = a.astype(np.uint64) + np.asarray(b, dtype=np.uint64)
+    return np.where(r > np.uint64(q), r - np.uint64(q), r)
+
+
+def poly_add_integer(a, b, q):
+    """poly_add_integer, poly_arithmetic.cuh:156-166: the same with a scalar b"""
+    return poly_add(a, np.uint64(b), q)
+
+
+def poly_sub(a, b, q):
+    """poly_sub, poly_arithmetic.cuh:168-179: ra = a[i]; if (ra < b[i]) ra += q; a[i] = ra  -- b is never subtracted"""
+    a = a.astype(np.uint64)
+    return np.where(a < b.astype(np.uint64), a + np.uint64(q), a)
+
+
+def poly_negate(a, q):
+    """poly_negate, poly_arithmetic.cuh:334-338: a[i] = q - a[i]; a[i] *= (a[i] != q)"""
+    r = np.uint64(q) - a.astype(np.uint64)
+    return np.where(r == np.uint64(q), np.uint64(0), r)
+
+
+def poly_mul_int_t(a, b, t):
+    """mod_t, poly_arithmetic.cuh:128-142: the low 64 bits of a[i] * b, masked with t - 1 held in a 32-bit `unsigned`"""
+    with np.errstate(over="ignore"):
+        lo = a.astype(np.uint64) * np.uint64(b)
+    return lo & np.uint64((int(t) - 1) & 0xffffffff)
+
+
 def ref_polymul(a, b, q):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     b = np.ascontiguousarray(b, dtype=np.uint64)

@@ -137,24 +137,47 @@ def test_library_build_rejects_experiment_switches(tmp_path):
 
 
 @pytest.fixture(scope="module")
-def n15_compile(tmp_path_factory):
-    """ONE compilation of kernels_fast_n15.hip (about two minutes) serves the scratch check and the VALU-ceiling drift check:
-    compiler remarks on stdout of tools/kernel_resources.py, the gfx950 assembly beside it."""
+def kernel_compiles(tmp_path_factory):
+    """ONE compilation per translation unit of the throughput kernels (n = 2^11 .. 2^16), all six at once (about two minutes on 8
+    cores): compiler remarks on stdout of tools/kernel_resources.py for the scratch check of every size, and the gfx950 assembly of
+    the n = 2^15 unit for the VALU-ceiling drift check."""
     tool = os.path.join(ROOT, "tools", "kernel_resources.py")
-    src = os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n15.hip")
     asm = str(tmp_path_factory.mktemp("n15") / "n15.s")
-    r = subprocess.run([sys.executable, tool, src, "15", "--require-no-scratch", "15", "--asm-out", asm], capture_output=True, text=True, timeout=1200)
-    return r, asm
+    procs = {}
+    for tag in ("11", "12", "13", "14", "15", "16"):
+        src = os.path.join(ROOT, "ntt-cuda_amd", "csrc", "kernels_fast_n%s.hip" % tag)
+        # (n = 2^16, beyond the reference's dispatch: its forward kernels are checked; k_inverse15_split<4, false, true> -- general 60-bit
+        # primes with the pointwise factor -- keeps 12 bytes, listed by the tool, a known leftover)
+        cmd = [sys.executable, tool, src, "", "--require-no-scratch", "k_forward15" if tag == "16" else "k_"] + (["--asm-out", asm] if tag == "15" else [])
+        procs[tag] = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    out = {}
+    for tag, p in procs.items():
+        text, _ = p.communicate(timeout=1800)
+        out[tag] = (p.returncode, text)
+    return out, asm
 
 
-def test_n15_kernels_use_no_scratch(n15_compile):
-    """Every n = 2^15 kernel instantiation (18 persistent + 30 small-batch: headroom class x near / general prime) fits its
-    128-VGPR budget without scratch memory (compiler remarks; tools/kernel_resources.py).  Round 2 shipped the general-prime
-    inverse and fused kernels with 28-104 bytes of scratch per lane."""
-    r, _ = n15_compile
-    rows = [l for l in r.stdout.splitlines() if "VGPRs" in l]
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert len(rows) == 48, len(rows)
+@pytest.fixture(scope="module")
+def n15_compile(kernel_compiles):
+    return kernel_compiles
+
+
+def test_throughput_kernels_use_no_scratch(kernel_compiles):
+    """EVERY instantiation of the throughput kernels -- persistent, fused-product and small-batch kernels of n = 2^11 .. 2^15 in every
+    headroom class (6, 4, 3, 2) x near / general prime, and the n = 2^16 split / pair kernels -- fits its VGPR budget without scratch
+    memory (compiler remarks; tools/kernel_resources.py).  Round 2 shipped the general-prime inverse and fused kernels of n = 2^15 with
+    28-104 bytes of scratch per lane, round 3 k_inverse<13|14, 4, false> with 12."""
+    out, _ = kernel_compiles
+    want = {"11": 56, "12": 56, "13": 56, "14": 56, "15": 56}      # 8 kernels x (classes 6, 4, 3, 2 near-2^k + 6, 4, 2 general)
+    for tag, (rc, text) in out.items():
+        rows = [l for l in text.splitlines() if "VGPRs" in l]
+        assert rc == 0, (tag, text[-3000:])
+        if tag in want:
+            assert len(rows) == want[tag], (tag, len(rows))
+        else:
+            assert len(rows) >= 18, (tag, len(rows))
+            spilling = [l.split()[0] + l.split()[1] + l.split()[2] for l in rows if "scratch    0 B" not in l]
+            assert all(x.startswith("k_inverse15_split<4,false,true>") for x in spilling), spilling
 
 
 def test_valu_ceiling_profile_matches_shipped_kernels(n15_compile):

@@ -184,3 +184,40 @@ def test_per_prime_literal_routing_on_the_kat1_moduli(native, oracle, gpu):
     want = oracle.inverse_batch(oracle.pointwise_batch(oracle.forward_batch(a.copy(), prm), bh, prm), prm)
     assert np.array_equal(native.to_host(da).reshape(-1), want.reshape(-1))
     ctx.close()
+
+
+def test_elementwise_wrappers_match_the_reference_arithmetic(native, oracle, gpu):
+    """poly_arithmetic.cuh:312-352 -- poly_add_device, poly_mul_int_t, poly_sub_device, poly_negate_device,
+    poly_add_integer_device -- against numpy restatements of the reference kernels (:128-179,334-338), including their quirks:
+    `>` in the additions (a sum equal to q stays q), poly_sub never subtracting, 0 -> 0 in the negation, the 32-bit mask of mod_t."""
+    import torch
+    rng = np.random.default_rng(5)
+    for n, q in ((2048, P.REF_PARAMS[2048][0]), (32768, P.Q60[0]), (4096, P.EDGE_PRIMES[61][0])):
+        a = rng.integers(0, q, size=n, dtype=np.uint64)
+        b = rng.integers(0, q, size=n, dtype=np.uint64)
+        a[:6] = [0, 1, q - 1, q - 1, 5, 7]
+        b[:6] = [0, q - 1, 1, q - 1, 7, 5]                      # sums 0, q, q, 2q - 2; differences both ways
+        s = torch.cuda.current_stream()
+        d = native.to_device(a); native.poly_add_device(d, native.to_device(b), n, s, q)
+        got = native.to_host(d)
+        assert np.array_equal(got, oracle.poly_add(a, b, q)) and got[1] == q and got[2] == q        # `>`: q is left alone
+        d = native.to_device(a); native.poly_sub_device(d, native.to_device(b), n, s, q)
+        got = native.to_host(d)
+        assert np.array_equal(got, oracle.poly_sub(a, b, q)) and got[4] == 5 + q and got[5] == 7   # (never a - b)
+        d = native.to_device(a); native.poly_negate_device(d, n, s, q)
+        got = native.to_host(d)
+        assert np.array_equal(got, oracle.poly_negate(a, q)) and got[0] == 0 and got[1] == q - 1
+        for k in (0, 1, q - 1, 12345678901234567):
+            d = native.to_device(a); native.poly_add_integer_device(d, k, n, s, q)
+            assert np.array_equal(native.to_host(d), oracle.poly_add_integer(a, k, q)), k
+        for t, k in ((1024, 3), (1 << 16, q - 5), (1 << 40, 0x123456789abcdef)):                   # t - 1 wider than 32 bits: truncated
+            d = native.to_device(a); native.poly_mul_int_t(d, k, n, s, t)
+            assert np.array_equal(native.to_host(d), oracle.poly_mul_int_t(a, k, t)), (t, k)
+    # odd word counts and tails (the wrappers take any n; the reference launches n / 256 blocks)
+    a = rng.integers(0, 1 << 50, size=1030, dtype=np.uint64)
+    d = native.to_device(a)[:1029]
+    native.poly_negate_device(d, 1029, torch.cuda.current_stream(), 1 << 50)
+    assert np.array_equal(native.to_host(d), oracle.poly_negate(a[:1029], 1 << 50))
+    L = native.lib()
+    assert L.mi355ntt_poly_add_raw(None, None, 16, None, 17) == native.EINVAL
+    assert L.mi355ntt_poly_negate_raw(native.vp(8), 16, None, 17) == native.EINVAL                 # misaligned

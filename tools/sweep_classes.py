@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Throughput of every n = 2^15 kernel class (headroom class hl6 / hl4 / hl2  x  near-2^k / general prime) at batch 1024.
+"""Throughput of every n = 2^15 kernel class (headroom class hl6 / hl4 / hl3 / hl2  x  near-2^k / general prime) at batch 1024.
 
 A context's class is decided by its primes (kernels_fast.hip, fast_tables_create): hl = min over primes of
-min(6, 64 - bit length) -> kernels <6>, <4> (hl 4, 5) or <2> (hl 2, 3); "near" only if EVERY prime is 2^k - delta with
+min(6, 64 - bit length) -> kernels <6>, <4> (hl 4, 5), <3> (hl 3, near-2^k primes only: round 4) or <2> (hl 2, and general primes at hl 3); "near" only if EVERY prime is 2^k - delta with
 delta < 2^24.  Each class below is timed with four primes of that class (the reference's / BASELINE's where they exist,
 otherwise the largest primes = 1 mod 2^16 below a bound far from a power of two, found here with Miller-Rabin; psi = the
 minimal primitive 2^16-th root, as the reference's are).  Every set is checked on the spot: inverse(forward(a)) == a and
 forward() of two sample polynomials against a Python evaluation of the transform at a few points.
 
-usage: python tools/sweep_classes.py [num=1024]     (GPU)        -> profiles/r03_kernel_classes.txt
+usage: python tools/sweep_classes.py [num=1024]     (GPU)        -> profiles/r04_kernel_classes.txt
 """
 import os
 import sys
@@ -86,7 +86,8 @@ def classes():
     c["hl6-general  (57-bit)"] = (primes_below(0xB3 << 49, 4), None)
     c["hl6-general  (58-bit)"] = (primes_below(0xB3 << 50, 4), None)
     c["hl4-general  (60-bit)"] = (primes_below(0xB3 << 52, 4), None)
-    c["hl2-near     (61-bit)"] = (primes_below(1 << 61, 4), None)
+    c["hl3-near     (61-bit)"] = (primes_below(1 << 61, 4), None)
+    c["hl2-general  (61-bit)"] = (primes_below(0xB3 << 53, 4), None)
     c["hl2-near     (62-bit)"] = (primes_below(1 << 62, 4), None)
     c["hl2-general  (62-bit)"] = (primes_below(0xB3 << 54, 4), None)
     return c
@@ -150,7 +151,7 @@ def main():
         tp = timeit(pair)
         tm = timeit(lambda: ctx.polymul_batch(a, b, num), reps=20, warm=40)
         hl = min(min(6, 64 - q.bit_length()) for q in qs)
-        kern = "<%d,%s>" % (6 if hl >= 6 else 4 if hl >= 4 else 2, "near" if "near" in name else "gen")
+        kern = "<%d,%s>" % (6 if hl >= 6 else 4 if hl >= 4 else 3 if (hl == 3 and "near" in name) else 2, "near" if "near" in name else "gen")
         rows.append((name, tp))
         print("  %-52s %-6s %9.4f %9.4f %12.0f %14.0f %9.2f" % (name, kern, tf * 1e3, ti * 1e3, num / tp, num / tm, num * N * 16 / ti / 1e12))
         ctx.close()
