@@ -58,9 +58,12 @@ def newest_profile(pattern):
 def rocprof_avg_ms(kernel):
     """average launch duration of `kernel` in the newest committed `rocprofv3 --kernel-trace --stats` summary of this workload
     (profiles/rNN_rocprofv3_summary_batch1024.txt, produced by tools/profile.sh 1024): (ms, file) or (None, None)"""
-    path = newest_profile("r%02d_rocprofv3_summary_batch1024.txt")
-    if not path:
+    # preferred: the trace of bench.py itself (`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras`);
+    # else the trace of the small driver at the same batch (tools/profile.sh 1024) -- whichever round is newest
+    cands = [p_ for p_ in (newest_profile("r%02d_rocprofv3_bench_py_stats.txt"), newest_profile("r%02d_rocprofv3_summary_batch1024.txt")) if p_]
+    if not cands:
         return None, None
+    path = max(cands, key=lambda p_: (os.path.basename(p_)[:3], "bench_py" in p_))
     import re
     for line in open(path):
         if ("::" + kernel + "<") in line:
