@@ -188,3 +188,36 @@ def test_valu_ceiling_profile_matches_shipped_kernels(n15_compile):
     assert os.path.exists(asm) and os.path.getsize(asm) > 1 << 20
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_ceiling.py"), "--asm", asm, "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_host_objects_under_asan_ubsan(native, tmp_path):
+    """The host side of the C ABI (capi.cpp, hostparams.cpp, bfv_host.cpp, shard.cpp) compiled by g++ with AddressSanitizer and
+    UndefinedBehaviorSanitizer and linked in front of libmi355ntt.so (which supplies the kernel launchers): tests/cpp/host_sanitize.cpp
+    walks the host-only helpers, every argument check and the creation-failure unwinding (no GPU here: mi355ntt_ctx_create fails
+    with MI355NTT_EHIP after building its host state).  No sanitizer report, exit status 0.  (Sanitizers on the CPU build only: GPU
+    sanitizers are not available on this pool.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-build sanitizer test (a sanitized process next to the GPU runtime is not what it is for)")
+    csrc = os.path.join(ROOT, "ntt-cuda_amd", "csrc")
+    flags = ["-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+             "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include")]
+    objs = []
+    procs = []
+    for f in ("capi", "hostparams", "bfv_host", "shard"):
+        o = str(tmp_path / (f + ".o"))
+        objs.append(o)
+        procs.append(subprocess.Popen(["g++"] + flags + ["-c", os.path.join(csrc, f + ".cpp"), "-o", o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+    exe = str(tmp_path / "host_sanitize")
+    libdir = os.path.join(ROOT, "ntt-cuda_amd")
+    r = subprocess.run(["g++"] + flags + [os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp")] + objs +
+                       ["-L", libdir, "-lmi355ntt", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, (r.stdout + r.stderr)[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
