@@ -691,6 +691,51 @@ def main():
 
         big4096, big8192 = large_batch(4096), large_batch(8192)
 
+        # ---- configs[3] as it would run on an 8-GPU node, DRY RUN on one GPU: the global batch of 8192 polynomials as 8 logical shards
+        # of 1024 (one context and three streams per shard, all on this device) through the C ABI's multi-device driver
+        # (mi355ntt_shards_*).  Not a scaling number: eight shards share one GPU.  What it shows: the partition, the fork / join and
+        # the pipelined scatter -> transform -> gather of a root-resident batch run, and cost nothing against the plain call.
+        def logical_shards(world=8, per=1024):
+            try:
+                total = world * per
+                ctxs = [ntt.NTTContext(n, Q60, PSI60, device=local) for _ in range(world)]
+                sh = ntt.ShardSet(ctxs, max_polys_per_piece=256)
+                full = synth_recipe(torch, ctx, total, n, dev, seed_base=31_000_001)
+                ref = full[:: total // 16].clone()
+                parts = [full[r * per:(r + 1) * per] for r in range(world)]       # (device-resident shards: views of one allocation)
+
+                def rate(fn, reps=6, warm=6):
+                    for _ in range(warm):
+                        fn()
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / reps
+
+                t_res = rate(lambda: sh.transform(ntt.OP_FORWARD_INVERSE, parts, total))
+                ok1 = bool(torch.equal(full[:: total // 16], ref))
+                t_stg = rate(lambda: sh.scatter_transform_gather(ntt.OP_FORWARD_INVERSE, full, total, chunks=4))
+                ok2 = bool(torch.equal(full[:: total // 16], ref))
+
+                def plain():
+                    ctx.forward_batch(full, total)
+                    ctx.inverse_batch(full, total)
+
+                t_plain = rate(plain)
+                sh.close()
+                for c_ in ctxs:
+                    c_.close()
+                del full
+                return {"dry_run": "8 logical shards on ONE GPU -- not a scaling number", "global_batch": total, "shards": world,
+                        "device_resident_shards_pairs_per_s": total / (t_res * 1e-3), "scatter_transform_gather_pairs_per_s": total / (t_stg * 1e-3),
+                        "single_call_pairs_per_s": total / (t_plain * 1e-3), "round_trip_ok": ok1 and ok2}
+            except Exception as exc:        # never let an optional leg break the contract line
+                return {"error": repr(exc)}
+
+        cfg3 = logical_shards()
+
         # ---- sustained run with package power / shader clock sampled (the kernels sit at the package power cap) ----
         power = None
         try:
@@ -788,6 +833,7 @@ def main():
         out["extras"] = {"config2_fused_polymul_batch256_per_s": 256 / (mul_ms * 1e-3), "config2_fused_polymul_ms": mul_ms,
                          "n65536_batch512": n16,
                          "n32768_batch4096": big4096, "n32768_batch8192": big8192,
+                         "configs3_global_batch_as_8_logical_shards": cfg3,
                          "power_sustained": power,
                          "fused_polymul_headline_batch": polymul,
                          "latency_compiled_cpp": cpp_lat,

@@ -221,3 +221,32 @@ def test_elementwise_wrappers_match_the_reference_arithmetic(native, oracle, gpu
     L = native.lib()
     assert L.mi355ntt_poly_add_raw(None, None, 16, None, 17) == native.EINVAL
     assert L.mi355ntt_poly_negate_raw(native.vp(8), 16, None, 17) == native.EINVAL                 # misaligned
+
+
+def test_configs3_global_batch_8192_as_8_shards_on_one_gpu(native, oracle, gpu):
+    """BASELINE configs[3] at its FULL global batch (n = 32768, 4-prime RNS, 8192 polynomials = 2 GiB), resident on the one GPU: the
+    whole-batch call against the 8-shard decomposition the 8-GPU run would use (mi355ntt_shards_transform over eight contexts), word
+    for word over all 2^28 coefficients, the round trip, and a sample of polynomials against the oracle."""
+    import torch
+    n, qs, psis, num, world = 32768, P.Q60, P.PSI60, 8192, 8
+    ctxs = [native.NTTContext(n, qs, psis) for _ in range(world)]
+    a = torch.empty((num, n), dtype=torch.int64, device=gpu)
+    ctxs[0].synth_splitmix(a, num, 1)
+    whole = a.clone()
+    ctxs[0].forward_batch(whole, num)
+    sh = native.ShardSet(ctxs)
+    shards = a.clone()
+    parts = [shards[r * 1024:(r + 1) * 1024] for r in range(world)]
+    assert [native.shard_range(num, 4, r, world) for r in range(world)] == [(r * 1024, 1024) for r in range(world)]
+    sh.transform(native.OP_FORWARD, parts, num)
+    assert torch.equal(shards, whole)
+    sh.transform(native.OP_INVERSE, parts, num)
+    assert torch.equal(shards, a)
+    prm = oracle.Params(n, qs, psis)
+    host = oracle.synth_batch(n, num, qs, 1).reshape(num, n)
+    for y in (0, 1023, 1024, 4097, 8191):
+        assert np.array_equal(native.to_host(a[y].contiguous()), host[y])
+        assert np.array_equal(native.to_host(whole[y].contiguous()), oracle.forward(host[y], prm, y % 4)), y
+    sh.close()
+    for c in ctxs:
+        c.close()
