@@ -475,7 +475,7 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
         return flags + f;
     };
     unsigned it = 0;
-    // the partner has read the input under this result?  (long since, normally.  A partner that never shows up -- tens of seconds --
+    // the partner has read the input under this result?  (long since, normally.  A partner that never shows up -- 30 s of wall clock, kPairWatchdogTicks --
     // means the grid is not resident as a whole, which the launch rules exclude: abort the kernel, loudly, rather than hang or
     // store over words the partner still needs)
     auto wait_for_partner = [&]() {

@@ -638,7 +638,7 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
             if constexpr (PAIR) {
                 // V of the next polynomial in front of the stores (results return in order: behind them it would wait for their
                 // drain), then: has the partner read the input under this result?  (long since, normally; a partner that never
-                // shows up -- tens of seconds -- means the grid is not resident as a whole: abort loudly rather than hang)
+                // shows up -- 30 s of wall clock, kPairWatchdogTicks -- means the grid is not resident as a whole: abort loudly rather than hang)
                 issue_loads_v(more ? y + stride : y, more);
                 unsigned* const pf = flag_at(1u - h);
                 if (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
