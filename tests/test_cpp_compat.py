@@ -66,3 +66,31 @@ def test_bfv_demo_batched_drivers(native, gpu):
     r = subprocess.run([build_demo(native), "5", "24"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Decryption is correct" in r.stdout and "Batched decryption is correct" in r.stdout
+
+
+SH_SRC = os.path.join(ROOT, "tests", "cpp", "shards_test.cpp")
+SH_EXE = os.path.join(ROOT, "tests", "cpp", "shards_test")
+
+
+def build_shards(native):
+    hdr = os.path.join(ROOT, "include", "mi355ntt.h")
+    if not os.path.exists(SH_EXE) or os.path.getmtime(SH_EXE) < max(os.path.getmtime(SH_SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-x", "hip", "--offload-arch=gfx950", SH_SRC, "-x", "none",
+                               "-L", os.path.join(ROOT, "ntt-cuda_amd"), "-lmi355ntt", "-Wl,-rpath," + os.path.join(ROOT, "ntt-cuda_amd"),
+                               "-o", SH_EXE])
+    return SH_EXE
+
+
+def test_shards_program_builds(native):
+    """CPU: a C++ program against the multi-device driver and the element-wise wrappers compiles and links against the C ABI alone."""
+    assert os.path.exists(build_shards(native))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,num", [(4, 600), (8, 37), (1, 64)])
+def test_shards_program_runs(native, gpu, world, num):
+    """mi355ntt_shards_scatter_transform_gather / _transform with `world` logical shards on the one GPU against the whole-batch
+    call, and poly_add_device ... poly_mul_int_t against the reference's arithmetic, from compiled C++."""
+    r = subprocess.run([build_shards(native), str(world), str(num)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "errors = 0" in r.stdout
