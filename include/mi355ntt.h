@@ -85,7 +85,8 @@ int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt
  * kinds (the reference's own decryption_test.cu set: primes 0 and 2 exact, prime 1 not) only the inexact primes' polynomials take
  * the literal kernels -- each call gathers them into a buffer the context owns (allocated at creation: no allocation at call
  * time), the throughput kernels transform the batch, the literal kernels the gathered rows, which are copied back; calls on
- * different streams take turns on that buffer in stream order (an event, no host synchronisation).  n = 65536 contexts with an
+ * different streams take turns on that buffer in stream order (an event, no host synchronisation; a capturing stream takes no part
+ * in that hand-over: while its graph runs, the context's mixed calls must all be the graph's own).  n = 65536 contexts with an
  * inexact prime stay literal as a whole.
  * ---------------------------------------------------------------------------------------------- */
 #define MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES 1u

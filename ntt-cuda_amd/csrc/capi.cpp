@@ -96,7 +96,11 @@ static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsig
     mi355ntt_ctx::Mixed& mx = c->mix;
     std::lock_guard<std::mutex> lock(mx.m);
     hipError_t e;
-    if (mx.used && (e = hipStreamWaitEvent(s, mx.last, 0)) != hipSuccess) return e;
+    // (a capturing stream takes no part in the event hand-over -- an event recorded outside the capture cannot be waited for inside
+    // it, and one recorded inside means nothing outside: while such a graph runs, the context's mixed calls must all be its own)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!capturing && mx.used && (e = hipStreamWaitEvent(s, mx.last, 0)) != hipSuccess) return e;
     const unsigned G = mx.rows_per_prime;
     const size_t row = (size_t)c->n * sizeof(u64);
     const u64* tabs = inverse ? c->d_psiinv : c->d_psi;
@@ -127,6 +131,7 @@ static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsig
             if ((e = hipMemcpy2DAsync(chunk + (size_t)r * c->n, division * row, buf, row, row, rows, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
         }
     }
+    if (capturing) return hipSuccess;
     mx.used = (hipEventRecord(mx.last, s) == hipSuccess);
     if (!mx.used) (void)hipStreamSynchronize(s);
     return hipSuccess;
