@@ -385,8 +385,14 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
-    if world > 1:
+    # MI355NTT_BENCH_FORCE_PG=1: join a process group even at world size 1, so that the collective bracket of the N > 1 path (RCCL
+    # barrier, MAX all-reduce, destroy before the CPU leg) runs on a one-GPU box (tests/test_gpu_round4.py); never set by the driver
+    use_pg = world > 1 or os.environ.get("MI355NTT_BENCH_FORCE_PG") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
@@ -406,7 +412,7 @@ def main():
         ctx.inverse_batch(a, batch)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -438,7 +444,7 @@ def main():
     e_end.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -858,7 +864,7 @@ def main():
                 ctx.forward_batch(piece, count)
                 ctx.inverse_batch(piece, count)
 
-            if world == 1:
+            if world == 1 and not use_pg:
                 e2e = lambda: tf(full.clone(), total)
             else:
                 e2e = lambda: shard.scatter_transform_gather(full, total, n, P, tf, chunks=4, src=0, device=dev, inplace=True)
@@ -869,7 +875,7 @@ def main():
                 e2e()
             barrier()
             el = time.perf_counter() - t0
-            if world > 1:
+            if use_pg:
                 tt = torch.tensor([el], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
@@ -878,7 +884,7 @@ def main():
         except Exception as exc:            # never let the optional leg break the contract line
             out["end_to_end"] = {"error": repr(exc)}
     ctx.close()
-    if world > 1:
+    if use_pg:
         # every rank leaves the collective layer BEFORE rank 0's multi-second CPU leg: nobody sits in an RCCL barrier meanwhile
         dist.barrier()
         dist.destroy_process_group()

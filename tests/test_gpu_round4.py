@@ -250,3 +250,19 @@ def test_configs3_global_batch_8192_as_8_shards_on_one_gpu(native, oracle, gpu):
     sh.close()
     for c in ctxs:
         c.close()
+
+
+def test_bench_collective_bracket_over_rccl_world_size_1(native, gpu):
+    """bench.py's N > 1 bracket -- init_process_group("nccl"), barrier + synchronize on both sides of the timed region, the MAX
+    all-reduce of the elapsed time, barrier + destroy_process_group before the CPU leg, the --end-to-end leg -- executed over RCCL on the
+    one GPU (MI355NTT_BENCH_FORCE_PG=1 joins a process group at world size 1).  Not a scaling number; the line must come out whole."""
+    import json
+    env = dict(os.environ, MI355NTT_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--batch", "256", "--no-extras",
+                        "--no-cpu-baseline", "--end-to-end"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+    assert "error" not in out.get("end_to_end", {}), out.get("end_to_end")
