@@ -772,6 +772,15 @@ def main():
         except Exception as exc:
             power = {"error": repr(exc)}
         assert torch.equal(a, a0)
+        # the VALU ceiling once more at the clock the chip HOLDS under this load (the clock probe above runs behind the launches, when
+        # the load is gone and the clock has already jumped: it reads ~2.4 GHz where rocm-smi shows ~2.25 GHz during the run)
+        if isinstance(power, dict) and power.get("sclk_mhz_mean") and valu:
+            cf = valu.get("k_forward15", {}).get("cycles_per_polynomial_per_cu")
+            ci = valu.get("k_inverse15", {}).get("cycles_per_polynomial_per_cu")
+            if cf and ci:
+                at = cus * power["sclk_mhz_mean"] * 1e6 / (cf + ci)
+                out["roofline"]["valu_ceiling_pairs_per_s_at_sustained_sclk"] = at
+                out["roofline"]["pair_frac_of_valu_ceiling_at_sustained_sclk"] = pairs_per_s / at
         one = synth(torch, 1, n, Q60[:1], dev, seed=9)
 
         def lat(fn):
