@@ -32,7 +32,7 @@
     defined(MI355NTT_PSPLIT_R1) || defined(MI355NTT_PSPLIT_R2) || defined(MI355NTT_PSPLIT_R3) || defined(MI355NTT_PSPLIT_I1) || \
     defined(MI355NTT_PSPLIT_I2) || defined(MI355NTT_PSPLIT_I3) || defined(MI355NTT_STAGGER_FWD) || defined(MI355NTT_STAGGER_INV) || \
     defined(MI355NTT_STAGGER_FWD_MULTI) || defined(MI355NTT_STAGGER_INV_MULTI) || defined(MI355NTT_STAGGER_MUL) || \
-    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_AUX_ST) || defined(MI355NTT_INV_DESCENDING)
+    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_AUX_ST) || defined(MI355NTT_INV_DESCENDING) || defined(MI355NTT_CANON_SIGN)
 #error "MI355NTT_* experiment switches are for measurement builds only: add -DMI355NTT_LAB (tools/build_kbench.sh); a library build must not define them"
 #endif
 #endif
@@ -349,7 +349,23 @@ __device__ __forceinline__ u64 mul_fold_near(u64 x, u64 b, const PrimeDev& p)
 }
 
 // [0, 2q) -> [0, q)
-__device__ __forceinline__ u64 canon_2q(u64 x, u64 q) { return x >= q ? x - q : x; }
+// MI355NTT_CANON_SIGN (lab switch, round 4): x - q as ONE 64-bit add of 2^64 - q (v_lshl_add_u64) and the select on its sign -- x < 2q <
+// 2^63, so x - q is negative exactly when x < q -- instead of a 64-bit compare, a subtract pair and the select.
+#ifndef MI355NTT_CANON_SIGN
+#define MI355NTT_CANON_SIGN 0
+#endif
+__device__ __forceinline__ u64 canon_2q(u64 x, u64 q)
+{
+#if MI355NTT_CANON_SIGN
+    u64 t;
+    const u64 nq = 0ULL - q;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(x), "s"(nq));      // (as C++ the compiler goes back to compare + subtract pair)
+    const int th = (int)hi32(t);
+    return th < 0 ? x : t;
+#else
+    return x >= q ? x - q : x;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // compile-time bound tracking
