@@ -88,17 +88,18 @@ __global__ void __launch_bounds__(1024) k_issue(Out* out, unsigned long long win
 
 typedef void (*kern_t)(Out*, unsigned long long, unsigned);
 
+static int g_reps = 2, g_wps_lo = 1;      // sustained mode: many long windows back to back at 4 waves per SIMD only
 static void run(const char* name, kern_t k, int per_op, unsigned long long window_us)
 {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("%-34s", name);
-    for (int wps = 1; wps <= 4; wps++) {
+    for (int wps = g_wps_lo; wps <= 4; wps++) {
         const int grid = prop.multiProcessorCount, block = 256 * wps;
         const size_t nw = (size_t)grid * block / 64;
         Out* d;
         CK(hipMalloc(&d, (nw + 1) * sizeof(Out)));
-        for (int rep = 0; rep < 2; rep++) {
+        for (int rep = 0; rep < g_reps; rep++) {
             hipLaunchKernelGGL(k, dim3(grid), dim3(block), 0, 0, d, window_us * 100ull, 1u);
             CK(hipDeviceSynchronize());
         }
@@ -139,6 +140,18 @@ int main(int argc, char** argv)
         {"v_ashrrev_i32", k_issue<35>, 1}, {"v_cmp_ge_u64 + 2 v_cndmask (triple)", k_issue<36>, 1},
     };
     printf("# shader cycles per wave-instruction per SIMD (pairs count as one), 1..4 waves per SIMD, %llu us windows\n", win);
+    if (argc > 2) {
+        // sustained mode: ubench_issue <window_us> <reps> <op index> ...: the named ops only, 4 waves per SIMD, `reps` windows back to back
+        // (e.g. 20000 us x 150 = 3 s per op) -- run it next to a rocm-smi sampler to read the package power a full-rate stream of ONE
+        // instruction draws (tools/exp_r04e.sh)
+        g_reps = atoi(argv[2]);
+        g_wps_lo = 4;
+        for (int i = 3; i < argc; i++) {
+            const int k = atoi(argv[i]);
+            if (k >= 0 && k < (int)(sizeof(ops) / sizeof(ops[0]))) { printf("[%d] ", k); run(ops[k].n, ops[k].k, ops[k].per, win); fflush(stdout); }
+        }
+        return 0;
+    }
     for (auto& o : ops) run(o.n, o.k, o.per, win);
     return 0;
 }
