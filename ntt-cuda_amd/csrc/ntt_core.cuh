@@ -32,7 +32,7 @@
     defined(MI355NTT_PSPLIT_R1) || defined(MI355NTT_PSPLIT_R2) || defined(MI355NTT_PSPLIT_R3) || defined(MI355NTT_PSPLIT_I1) || \
     defined(MI355NTT_PSPLIT_I2) || defined(MI355NTT_PSPLIT_I3) || defined(MI355NTT_STAGGER_FWD) || defined(MI355NTT_STAGGER_INV) || \
     defined(MI355NTT_STAGGER_FWD_MULTI) || defined(MI355NTT_STAGGER_INV_MULTI) || defined(MI355NTT_STAGGER_MUL) || \
-    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_AUX_ST) || defined(MI355NTT_INV_DESCENDING) || defined(MI355NTT_CANON_SIGN)
+    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_AUX_ST) || defined(MI355NTT_INV_DESCENDING) || defined(MI355NTT_CANON_SIGN) || defined(MI355NTT_NEAR60_N1_SHIFT)
 #error "MI355NTT_* experiment switches are for measurement builds only: add -DMI355NTT_LAB (tools/build_kbench.sh); a library build must not define them"
 #endif
 #endif
@@ -250,10 +250,22 @@ __device__ __forceinline__ u64 shoup_rem_chain(u64 y, u64 w, u64 h, u64 nq, u64 
     const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w), n0 = lo32(nq), n1 = hi32(nq);
     const u32 h0 = lo32(h), h1 = hi32(h);
     const u64 acc = mad32(h0, n0, mad32(y0, w0, base));
+#ifdef MI355NTT_NEAR60_N1_SHIFT
+    // lab switch (round 4, energy experiment; 60-bit near-2^k primes only: the high word of 2^64 - q is 0xF0000000): h0 * n1 mod 2^32 is
+    // -(h0 << 28) -- a shift and a subtract (cheap instructions, profiles/r04_power_cap_and_overlap.txt batch E) instead of one multiply-add
+    (void)n1;
+    const u64 c = mad32_chain<true>(h1, n0, mad32_chain<TWS>(y1, w0, mad32_chain0<TWS>(y0, w1)));
+    u32 xh = hi32(acc), sh;
+    asm("v_lshlrev_b32 %0, 28, %1" : "=v"(sh) : "v"(h0));
+    asm("v_add_u32 %0, %0, %1" : "+v"(xh) : "v"(lo32(c)));
+    asm("v_sub_u32 %0, %0, %1" : "+v"(xh) : "v"(sh));
+    return ((u64)xh << 32) | lo32(acc);
+#else
     const u64 c = mad32_chain<true>(h1, n0, mad32_chain<true>(h0, n1, mad32_chain<TWS>(y1, w0, mad32_chain0<TWS>(y0, w1))));
     u32 xh = hi32(acc);
     asm("v_add_u32 %0, %0, %1" : "+v"(xh) : "v"(lo32(c)));     // (as C++ the compiler re-associates it into a 64-bit add of {0, c})
     return ((u64)xh << 32) | lo32(acc);
+#endif
 }
 // y*w + h*(2^64 - q) + base  (mod 2^64); without base: congruent to y*w and in [0, 4q).  nq is always scalar (PrimeDev).
 template <bool TWS>
