@@ -908,7 +908,8 @@ inline bool use_latency_path(unsigned num, bool fused)
 }
 
 // the context's kernel class (FastTables::hl: bits 0-3 headroom class, bit 4 every prime near 2^k) as compile-time arguments.
-// Classes: 6 (<= 58-bit moduli: no intermediate reduction), 4 (59/60-bit: one every 2-3 stages), 3 (61-bit near-2^k, round 4: 8 q < 2^64, so the
+// Classes: 6 (<= 58-bit moduli: no intermediate reduction), 5 (59-bit near-2^k, round 4: one partial reduction every 7 forward / 3 inverse stages
+// instead of every 3 / 2), 4 (59/60-bit: one every 2-3 stages), 3 (61-bit near-2^k, round 4: 8 q < 2^64, so the
 // lazy three-product quotient estimate with values in [0, 4q) still fits -- one partial reduction per stage, but no 64 x 64 high
 // product; the reference's decryption modulus gamma is 61-bit, demo.cu:93) and 2 (62-bit: exact quotients, values in [0, 2q)).
 // WITH3 = false (the n = 2^16 split / pair kernels): 61-bit moduli stay in class 2 there.
@@ -920,6 +921,7 @@ inline void dispatch_class(int hl, F&& f)
     using std::integral_constant;
     if (near) {
         if (h >= 6) f(integral_constant<int, 6>{}, integral_constant<bool, true>{});
+        else if (WITH3 && h == 5) f(integral_constant<int, WITH3 ? 5 : 4>{}, integral_constant<bool, true>{});
         else if (h >= 4) f(integral_constant<int, 4>{}, integral_constant<bool, true>{});
         else if (WITH3 && h == 3) f(integral_constant<int, WITH3 ? 3 : 2>{}, integral_constant<bool, true>{});
         else f(integral_constant<int, 2>{}, integral_constant<bool, true>{});

@@ -86,6 +86,7 @@ def classes():
     c["hl6-general  (57-bit)"] = (primes_below(0xB3 << 49, 4), None)
     c["hl6-general  (58-bit)"] = (primes_below(0xB3 << 50, 4), None)
     c["hl4-general  (60-bit)"] = (primes_below(0xB3 << 52, 4), None)
+    c["hl5-near     (59-bit)"] = (primes_below(1 << 59, 4), None)
     c["hl3-near     (61-bit)"] = (primes_below(1 << 61, 4), None)
     c["hl2-general  (61-bit)"] = (primes_below(0xB3 << 53, 4), None)
     c["hl2-near     (62-bit)"] = (primes_below(1 << 62, 4), None)
@@ -151,7 +152,7 @@ def main():
         tp = timeit(pair)
         tm = timeit(lambda: ctx.polymul_batch(a, b, num), reps=20, warm=40)
         hl = min(min(6, 64 - q.bit_length()) for q in qs)
-        kern = "<%d,%s>" % (6 if hl >= 6 else 4 if hl >= 4 else 3 if (hl == 3 and "near" in name) else 2, "near" if "near" in name else "gen")
+        kern = "<%d,%s>" % (6 if hl >= 6 else 5 if (hl == 5 and "near" in name) else 4 if hl >= 4 else 3 if (hl == 3 and "near" in name) else 2, "near" if "near" in name else "gen")
         rows.append((name, tp))
         print("  %-52s %-6s %9.4f %9.4f %12.0f %14.0f %9.2f" % (name, kern, tf * 1e3, ti * 1e3, num / tp, num / tm, num * N * 16 / ti / 1e12))
         ctx.close()
