@@ -329,13 +329,16 @@ KERNEL_FORMS = {
     "hl4-general": ([P.GENERAL_PRIMES[60][0], P.GENERAL_PRIMES[59][0], P.Q60[0]], [P.GENERAL_PRIMES[60][1], P.GENERAL_PRIMES[59][1], P.PSI60[0]]),
     "hl2-near": ([P.EDGE_PRIMES[62][0], P.EDGE_PRIMES[61][0]], [P.EDGE_PRIMES[62][1][32768], P.EDGE_PRIMES[61][1][32768]]),
     "hl2-general": ([P.GENERAL_PRIMES[62][0], P.Q60[1]], [P.GENERAL_PRIMES[62][1], P.PSI60[1]]),
+    # round 4: classes of their own for 61-bit and 59-bit near-2^k moduli (dispatch_class, kernels_fast_impl.cuh)
+    "hl3-near": ([P.EDGE_PRIMES[61][0]], [P.EDGE_PRIMES[61][1][32768]]),
+    "hl5-near": ([P.EDGE_PRIMES[59][0], P.EDGE_PRIMES[59][0]], [P.EDGE_PRIMES[59][1][32768], P.EDGE_PRIMES[59][1][32768]]),
 }
 
 
 @pytest.mark.parametrize("form", sorted(KERNEL_FORMS))
 @pytest.mark.parametrize("num", [7, 200, 300])
 def test_every_kernel_form_at_n32768_matches_oracle(native, oracle, gpu, form, num):
-    """n = 2^15 has six instantiations per kernel (headroom class x near-2^k or general prime: partial reduction, exact or
+    """n = 2^15 has eight instantiations per kernel (headroom class x near-2^k or general prime: partial reduction, exact or
     approximate quotient, fused butterfly) on two paths (the small-batch kernels of kernels_lat.cuh for 7 and -- just above one
     polynomial per CU -- 300 polynomials, the persistent single-pass kernels for 200; use_latency_path, kernels_fast_impl.cuh):
     every one of them against the oracle, with adversarial coefficients (0, 1, q-1, q-2) mixed into the random ones."""
