@@ -164,6 +164,22 @@ def test_per_prime_literal_routing_on_the_kat1_moduli(native, oracle, gpu):
     ctx.forward_batch(da, num, stream=s1); ctx.forward_batch(db, num, stream=s2)
     torch.cuda.synchronize()
     assert np.array_equal(native.to_host(da).reshape(num, n), want_a) and np.array_equal(native.to_host(db).reshape(num, n), want_b)
+    # captured into a hipGraph (strided copies become memcpy nodes; the event hand-over is left out inside a capture) and replayed
+    num = 300
+    a = oracle.synth_batch(n, num, KAT_Q, 91).reshape(num, n)
+    want = oracle.inverse_batch(oracle.forward_batch(a.copy(), prm), prm).reshape(num, n)
+    d = native.to_device(a)
+    src = native.to_device(a)
+    torch.cuda.synchronize()
+    g, cs = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=cs):
+        ctx.forward_batch(d, num)
+        ctx.inverse_batch(d, num)
+    for _ in range(2):
+        d.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(native.to_host(d).reshape(num, n), want), "mixed context, graph replay"
     # single-polynomial entry points pick the kernel class of their prime; a division that covers only exact primes runs fast kernels
     for i in range(3):
         x = oracle.synth_batch(n, 1, [KAT_Q[i]], 9 + i)[0]
