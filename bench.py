@@ -48,11 +48,15 @@ BYTES_PER_TRANSFORM = 2 * 32768 * 8   # one in-place transform reads and writes 
 
 def newest_profile(pattern):
     """newest committed profile of a kind: `pattern` holds one %d for the round number (profiles/traffic_r%02d.json ...)"""
-    for rnd in range(9, 0, -1):
-        path = os.path.join(ROOT, "profiles", pattern % rnd)
-        if os.path.exists(path):
-            return path
-    return None
+    import glob
+    import re
+    rx = re.compile("^" + re.escape(pattern).replace(re.escape("%02d"), r"(\d+)").replace(re.escape("%d"), r"(\d+)") + "$")
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "*")):
+        m = rx.match(os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    return best[1] if best else None
 
 
 def rocprof_avg_ms(kernel):
@@ -63,14 +67,17 @@ def rocprof_avg_ms(kernel):
     cands = [p_ for p_ in (newest_profile("r%02d_rocprofv3_bench_py_stats.txt"), newest_profile("r%02d_rocprofv3_summary_batch1024.txt")) if p_]
     if not cands:
         return None, None
-    path = max(cands, key=lambda p_: (os.path.basename(p_)[:3], "bench_py" in p_))
     import re
+    path = max(cands, key=lambda p_: (int(re.match(r"r(\d+)_", os.path.basename(p_)).group(1)), "bench_py" in p_))
     for line in open(path):
         if ("::" + kernel + "<") in line:
             m = re.search(r"avg_ns=([0-9.]+)", line)
             if m:
                 return float(m.group(1)) * 1e-6, os.path.relpath(path, ROOT)
     return None, None
+
+
+PROFILED_BATCH = 1024       # polynomials per launch in the committed rocprofv3 summaries (bench.py's default batch; tools/profile.sh 1024)
 
 
 class PowerSampler:
@@ -389,10 +396,19 @@ def main():
     # barrier, MAX all-reduce, destroy before the CPU leg) runs on a one-GPU box (tests/test_gpu_round4.py); never set by the driver
     use_pg = world > 1 or os.environ.get("MI355NTT_BENCH_FORCE_PG") == "1"
     if use_pg:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", str(world))
+        if world == 1:
+            # (MI355NTT_BENCH_FORCE_PG at world size 1: a rendezvous of its own)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        else:
+            # world > 1: the launcher's variables or nothing -- a rank that guessed its own port and rank would hang the others
+            missing = [v for v in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE") if v not in os.environ]
+            if missing:
+                sys.stderr.write("bench.py: WORLD_SIZE=%d but %s not set -- launch the ranks with torch.distributed.run (or run "
+                                 "bench.py --gpus N without a launcher: it spawns them itself)\n" % (world, ", ".join(missing)))
+                sys.exit(2)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
@@ -541,9 +557,11 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source, "kernel": dom_name,
                      "avg_launch_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "frac_rocprof": (alg_bytes / (rp_ms * 1e-3) / HBM_PEAK) if rp_ms else None,
-                     "frac_rocprof_source": ("%s: %s avg %.4f ms under rocprofv3 --kernel-trace (another run, another box; `frac` above is this run's "
-                                             "HIP-event time)" % (rp_file, dom_name, rp_ms)) if rp_ms else None,
+                     # the committed profile's own figure: its batch (PROFILED_BATCH) over its average launch time -- not this run's batch
+                     "committed_profile": ({"file": rp_file, "kernel": dom_name, "batch": PROFILED_BATCH, "avg_launch_ms": rp_ms,
+                                            "frac": PROFILED_BATCH * BYTES_PER_TRANSFORM / (rp_ms * 1e-3) / HBM_PEAK,
+                                            "note": "rocprofv3 --kernel-trace --stats of bench.py, another run on another box; `frac` above is this run's HIP-event time"}
+                                           if rp_ms else None),
                      "pair_frac_of_hbm_peak": pairs_per_s / world * 2 * BYTES_PER_TRANSFORM / HBM_PEAK,
                      "valu_ceiling_transforms_per_s": valu_ceiling,
                      "frac_of_valu_ceiling": (batch / (dom_ms * 1e-3) / valu_ceiling) if valu_ceiling else None,

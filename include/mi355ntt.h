@@ -85,8 +85,9 @@ int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt
  * kinds (the reference's own decryption_test.cu set: primes 0 and 2 exact, prime 1 not) only the inexact primes' polynomials take
  * the literal kernels -- each call gathers them into a buffer the context owns (allocated at creation: no allocation at call
  * time), the throughput kernels transform the batch, the literal kernels the gathered rows, which are copied back; calls on
- * different streams take turns on that buffer in stream order (an event, no host synchronisation; a capturing stream takes no part
- * in that hand-over: while its graph runs, the context's mixed calls must all be the graph's own).  n = 65536 contexts with an
+ * different streams take turns on that buffer in stream order (an event, no host synchronisation, recorded on every way out of the
+ * call, errors included).  A call on a CAPTURING stream cannot join that hand-over, so it runs the literal kernels for all of its
+ * primes in place (the same words, no shared buffer): a replayed graph never touches the gather buffer.  n = 65536 contexts with an
  * inexact prime stay literal as a whole.
  * ---------------------------------------------------------------------------------------------- */
 #define MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES 1u
@@ -98,6 +99,11 @@ int mi355ntt_ctx_destroy(mi355ntt_ctx* ctx);
 /* 0: every prime on the throughput kernels; 1: the whole context on the literal (reference-arithmetic) kernels; 2: per-prime
  * routing, see above */
 int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* ctx);
+/* diagnostic: the arithmetic class the throughput kernels of this context were selected by -- bits 0-3: headroom = min over the
+ * primes of (64 - bit length), capped at 6 (values stay below 2^headroom q between partial reductions); bit 4: every prime is
+ * "near 2^k" (q = 2^k - d with d < 2^24, 2^(64-k) d + 2 d < 2^k and 2 d^2 + 3 d < 2^k: the 3-instruction fold replaces the general
+ * partial reduction).  tests/test_gpu_fuzz_moduli.py recomputes it for moduli drawn on both sides of every threshold. */
+int mi355ntt_ctx_kernel_class(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_n(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_num_primes(const mi355ntt_ctx* ctx);
 /* the device the context lives on.  Every launching call on a context (or on a BFV object) runs on THAT device: the
@@ -272,7 +278,10 @@ int mi355ntt_barrett_int_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi35
  * place in d_a; the BFV drivers above carry the same arithmetic fused into their own kernels).  The reference's words, quirks
  * included: poly_add / poly_add_integer reduce with `>` (a sum equal to q stays q, :144-166); poly_sub (:168-179) only adds q where
  * a[i] < b[i] and never subtracts b -- mirrored literally, it is what the reference computes; poly_negate maps 0 to 0 (:334-338);
- * poly_mul_int_t masks the low 64 bits of a[i] b with t - 1 held in a 32-bit register (:128-142).  Pointers 16-byte aligned. */
+ * poly_mul_int_t masks the low 64 bits of a[i] b with t - 1 held in a 32-bit register (:128-142).  Any pointer to 64-bit words is
+ * accepted, as by the reference (16-byte aligned ones run 16 bytes per lane).  One difference, deliberate: all n words are processed --
+ * the reference launches n / 256 blocks of 256 threads and leaves a tail of n % 256 words untouched (:314,324,329,342,347); its callers
+ * only pass ring degrees, which are multiples of 256. */
 int mi355ntt_poly_add_raw(mi355ntt_u64* d_a, const mi355ntt_u64* d_b, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q);          /* poly_add_device :312 */
 int mi355ntt_poly_mul_int_t_raw(mi355ntt_u64* d_a, mi355ntt_u64 b, unsigned n, mi355ntt_stream stream, mi355ntt_u64 t);             /* poly_mul_int_t :322 */
 int mi355ntt_poly_sub_raw(mi355ntt_u64* d_a, const mi355ntt_u64* d_b, unsigned n, mi355ntt_stream stream, mi355ntt_u64 q);          /* poly_sub_device :327 */

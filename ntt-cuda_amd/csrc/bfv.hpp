@@ -19,11 +19,12 @@ struct BfvPrime {
     u64 inv_q_last_mod_q;     // (q_last mod q_i)^-1 mod q_i             demo.cu:73-79
     u64 q_div_t;              // floor(q_i / t)                          demo.cu:84-88
     u64 half_last_mod_q;      // (q_last >> 1) mod q_i                   bfv_encryption.cuh:138
+    u64 m64;                  // floor((2^64 - 1) / q_i): exact x mod q_i for any 64-bit x (reduce64, kernels_bfv.hip) in place of the reference's `%`
 };
 
 struct BfvParams {
     unsigned n = 0, R = 0, r = 0;      // R = number of primes including the special last one, r = R - 1
-    u64 t = 0, gamma = 0, mu_gamma = 0, gamma_div_2 = 0;
+    u64 t = 0, gamma = 0, mu_gamma = 0, gamma_div_2 = 0, m64_gamma = 0;    // m64_gamma: floor((2^64 - 1) / gamma), see BfvPrime::m64
     unsigned gamma_bits = 0;
     u64 neg_inv_q_mod_t = 0, neg_inv_q_mod_gamma = 0;     // demo.cu:103-117
     u64 q_last = 0, half_q_last = 0;

@@ -32,6 +32,7 @@ int bfv_bootstrap(BfvParams* out, unsigned n, unsigned R, const u64* q, u64 t, u
     p.gamma_bits = gbits;                          // output_base_bit_lengths[1] (61 for the reference's gamma, demo.cu:100)
     p.mu_gamma = barrett_mu(gamma, gbits);         // demo.cu:218-226
     p.gamma_div_2 = gamma >> 1;                    // demo.cu:94
+    p.m64_gamma = ~0ULL / gamma;
     p.q_last = q[R - 1];
     p.half_q_last = p.q_last >> 1;
     const unsigned r = p.r;
@@ -52,6 +53,7 @@ int bfv_bootstrap(BfvParams* out, unsigned n, unsigned R, const u64* q, u64 t, u
         bp.k = bit_length(q[i]);
         bp.mu = barrett_mu(q[i], bp.k);
         bp.q_div_t = q[i] / t;                                 // demo.cu:84-88
+        bp.m64 = ~0ULL / q[i];
         if (i < r) {
             bp.prod_t_gamma_mod_q = (u64)(prod_t_gamma % q[i]);
             u64 punct = 1;                                     // demo.cu:262-276

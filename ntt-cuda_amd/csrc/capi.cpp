@@ -83,6 +83,7 @@ static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
 // residues r < division whose prime (base + r) is Barrett-inexact in a mixed context
 static unsigned inexact_residues(const mi355ntt_ctx* c, unsigned division, unsigned base)
 {
+    base &= ~kGuardBit;              // (checked raw calls carry the guard flag in the prime base, kernels.hpp)
     return c->mixed ? (c->inexact_mask >> base) & ((division >= 32 ? 0u : (1u << division)) - 1u) : 0u;
 }
 
@@ -93,14 +94,34 @@ static unsigned inexact_residues(const mi355ntt_ctx* c, unsigned division, unsig
 // enqueued on `s`; another stream's mixed call on the same context waits for this one's last event before it touches the buffer.
 static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsigned num, unsigned division, unsigned base, unsigned sub, hipStream_t s)
 {
+    // (a capturing stream cannot take part in the event hand-over -- an event recorded outside the capture cannot be waited for inside
+    // it, and one recorded inside means nothing outside -- so a replayed graph would share the gather buffer with other streams' calls
+    // unordered.  Under capture the whole call therefore runs the literal kernels in place on d_a: the reference's words for every
+    // prime (for the exact ones they ARE the throughput kernels' words), no shared buffer)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        if (base & kGuardBit) return hipSuccess;      // (checked raw call: raw_run's fallback leg, told to run unguarded, does the work)
+        const u64* t = (inverse ? c->d_psiinv : c->d_psi) + (size_t)base * c->n;
+        return inverse ? compat_inverse_batch(d_a, c->n, t, num, division, mods_from(c, base, division), s)
+                       : compat_forward_batch(d_a, c->n, t, num, division, mods_from(c, base, division), s);
+    }
+    // Checked raw calls (base carries kGuardBit; raw_run has compared the caller's table with the context's on the device): the
+    // throughput kernels skip themselves when the tables differ, and so must the literal kernels on the gathered rows -- they run
+    // under the INVERTED guard pair (words 2, 3 of the guard record, compat_guard_invert); the copies around them move untouched
+    // rows back where they came from, and raw_run's own fallback leg then transforms everything with the caller's table.
+    const unsigned pb = base & ~kGuardBit;
+    const unsigned* lit_guard = (base & kGuardBit) ? static_cast<const unsigned*>(c->fast.d_primes_alloc) + 2 : nullptr;
     mi355ntt_ctx::Mixed& mx = c->mix;
     std::lock_guard<std::mutex> lock(mx.m);
     hipError_t e;
-    // (a capturing stream takes no part in the event hand-over -- an event recorded outside the capture cannot be waited for inside
-    // it, and one recorded inside means nothing outside: while such a graph runs, the context's mixed calls must all be its own)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    if (!capturing && mx.used && (e = hipStreamWaitEvent(s, mx.last, 0)) != hipSuccess) return e;
+    if (mx.used && (e = hipStreamWaitEvent(s, mx.last, 0)) != hipSuccess) return e;         // (nothing enqueued yet)
+    // From here on work that reads or writes the gather buffer may sit on `s`: whatever happens, the next stream's call must wait for
+    // it.  `leave` records the hand-over event (or, if even that fails, drains the stream) on every way out, error or not.
+    auto leave = [&](hipError_t rc) {
+        mx.used = (hipEventRecord(mx.last, s) == hipSuccess);
+        if (!mx.used) (void)hipStreamSynchronize(s);
+        return rc;
+    };
     const unsigned G = mx.rows_per_prime;
     const size_t row = (size_t)c->n * sizeof(u64);
     const u64* tabs = inverse ? c->d_psiinv : c->d_psi;
@@ -112,11 +133,11 @@ static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsig
             if (!((sub >> r) & 1u)) continue;
             const unsigned rows = cnt > r ? (cnt - r + division - 1) / division : 0;
             if (rows && (e = hipMemcpy2DAsync(mx.d + (size_t)slot * G * c->n, row, chunk + (size_t)r * c->n, division * row, row, rows,
-                                              hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+                                              hipMemcpyDeviceToDevice, s)) != hipSuccess) return leave(e);
             slot++;
         }
         e = inverse ? fast_inverse_batch(c->fast, chunk, cnt, division, base, s) : fast_forward_batch(c->fast, chunk, cnt, division, base, s);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) return leave(e);
         slot = 0;
         for (unsigned r = 0; r < division; r++) {
             if (!((sub >> r) & 1u)) continue;
@@ -124,17 +145,14 @@ static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsig
             u64* buf = mx.d + (size_t)slot * G * c->n;
             slot++;
             if (!rows) continue;
-            const ModSet m1 = mods_from(c, base + r, 1);
-            e = inverse ? compat_inverse_batch(buf, c->n, tabs + (size_t)(base + r) * c->n, rows, 1, m1, s)
-                        : compat_forward_batch(buf, c->n, tabs + (size_t)(base + r) * c->n, rows, 1, m1, s);
-            if (e != hipSuccess) return e;
-            if ((e = hipMemcpy2DAsync(chunk + (size_t)r * c->n, division * row, buf, row, row, rows, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+            const ModSet m1 = mods_from(c, pb + r, 1);
+            e = inverse ? compat_inverse_batch(buf, c->n, tabs + (size_t)(pb + r) * c->n, rows, 1, m1, s, lit_guard)
+                        : compat_forward_batch(buf, c->n, tabs + (size_t)(pb + r) * c->n, rows, 1, m1, s, lit_guard);
+            if (e != hipSuccess) return leave(e);
+            if ((e = hipMemcpy2DAsync(chunk + (size_t)r * c->n, division * row, buf, row, row, rows, hipMemcpyDeviceToDevice, s)) != hipSuccess) return leave(e);
         }
     }
-    if (capturing) return hipSuccess;
-    mx.used = (hipEventRecord(mx.last, s) == hipSuccess);
-    if (!mx.used) (void)hipStreamSynchronize(s);
-    return hipSuccess;
+    return leave(hipSuccess);
 }
 
 static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
@@ -250,6 +268,7 @@ int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes, con
 }
 
 int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* c) { return !c ? 0 : c->literal ? 1 : c->mixed ? 2 : 0; }
+int mi355ntt_ctx_kernel_class(const mi355ntt_ctx* c) { return !c ? MI355NTT_EINVAL : c->fast.hl; }
 
 int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, const mi355ntt_u64* q, const mi355ntt_u64* psi,
                            int device, unsigned flags)
@@ -546,7 +565,7 @@ int mi355ntt_ctx_probed_clock_mhz(const mi355ntt_ctx* c, double* mhz)
 static int elementwise(int op, mi355ntt_u64* d_a, const mi355ntt_u64* d_b, bool need_b, mi355ntt_u64 scalar, mi355ntt_u64 q, unsigned n, mi355ntt_stream s)
 {
     if (!d_a || (need_b && !d_b) || q == 0) return MI355NTT_EINVAL;
-    if (((uintptr_t)d_a & 15u) || (need_b && ((uintptr_t)d_b & 15u))) return MI355NTT_EINVAL;      /* 16-byte accesses */
+    if (((uintptr_t)d_a & 7u) || (need_b && ((uintptr_t)d_b & 7u))) return MI355NTT_EINVAL;        /* words; 16-byte aligned pointers take the 16-byte kernel */
     (void)hipGetLastError();
     HIP_TRY(compat_elementwise(op, d_a, d_b, scalar, q, n, (hipStream_t)s));
     return MI355NTT_OK;
@@ -649,7 +668,8 @@ mi355ntt_ctx* raw_derive(int device, unsigned n, unsigned division, bool inverse
     u64 root[kMaxPrimes];
     for (unsigned i = 0; i < division; i++) {
         if (q[i] < 3 || !(q[i] & 1) || bits[i] != bit_length(q[i]) || mu[i] != barrett_mu(q[i], bits[i])) return nullptr;
-        if (!barrett_single_subtraction_exact(q[i], bits[i], mu[i])) return nullptr;
+        // (a Barrett-inexact modulus no longer sends the whole call to the literal kernels: the derived context routes per prime,
+        // as the reference's own decryption_test.cu:47-48 set through forwardNTT_batch needs it -- 2 of its 3 primes are exact)
         // entry n/2 of a table is root^bitrev(n/2) = root^1
         if (hipMemcpy(&root[i], d_tab + (size_t)i * n + n / 2, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
         if (root[i] == 0 || root[i] >= q[i]) return nullptr;
@@ -729,13 +749,19 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
     const mi355ntt_ctx* c = e ? e->ctx : nullptr;
     if (!c || (c->split16 && !e->trusted))
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
+    if (c->mixed && inexact_residues(c, division, 0) == (division >= 32 ? ~0u : (1u << division) - 1u))      // nothing for the throughput kernels
+        return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (e->trusted) return inverse ? run_inverse(c, d_a, num, division, 0, s) : run_forward(c, d_a, num, division, 0, s);
     hipError_t err;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (c->mixed && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)           // (no gather buffer under capture)
+        return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (!e->ev && (err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming)) != hipSuccess) return err;
     if (e->used && e->last_stream != s && (err = hipStreamWaitEvent(s, e->ev, 0)) != hipSuccess) return err;
     unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);
     if (++e->epoch == 0) e->epoch = 1;
     if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s)) != hipSuccess) return err;
+    if (c->mixed && (err = compat_guard_invert(guard, s)) != hipSuccess) return err;       // (words 2, 3: the gathered rows' literal kernels, run_mixed)
     err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
     if (err != hipSuccess) return err;
     err = inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s, guard) : compat_forward_batch(d_a, n, d_tab, num, division, m, s, guard);

@@ -65,6 +65,9 @@ hipError_t compat_synth_splitmix(u64* d_a, unsigned n, unsigned num, unsigned di
 hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_flag, hipStream_t s);
 // the same as a stream-ordered check: guard[0] = epoch, and guard[1] = epoch when the tables differ
 hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s);
+// guard[2], guard[3] <- a pair that is EQUAL exactly when guard[0] != guard[1] (tables equal): literal kernels launched with guard + 2 run
+// only when the throughput kernels run too (the literal share of a mixed context inside a checked raw call, capi.cpp run_mixed)
+hipError_t compat_guard_invert(unsigned* d_guard, hipStream_t s);
 
 // ---- throughput kernels (kernels_fast.hip) ----
 // Device tables private to the fast path.  Built once per context from the reference-format tables.

@@ -14,120 +14,206 @@ namespace {
 
 constexpr unsigned kBlock = 256;
 
+// V consecutive words per lane: V = 2 moves 16 bytes per lane and instruction (pointers 16-byte aligned: every device allocation
+// and every whole-polynomial offset is), V = 1 is the form for callers that hand over merely 8-byte aligned pointers.
+template <int V>
+__device__ __forceinline__ void ldv(u64 (&x)[V], const u64* __restrict__ p)
+{
+    if constexpr (V == 2) {
+        const ulonglong2 t = *reinterpret_cast<const ulonglong2*>(p);
+        x[0] = t.x; x[1] = t.y;
+    } else {
+        x[0] = p[0];
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(u64* __restrict__ p, const u64 (&x)[V])
+{
+    if constexpr (V == 2) *reinterpret_cast<ulonglong2*>(p) = make_ulonglong2(x[0], x[1]);
+    else p[0] = x[0];
+}
+
+// x mod q for ANY 64-bit x, exact -- the reference writes `%` (bfv_encryption.cuh:150,204; poly_arithmetic.cuh:252,262), which
+// gfx950 runs as a software division of some sixty instructions.  m64 = floor((2^64 - 1) / q) from the host: the estimate
+// e = floor(x m64 / 2^64) is the quotient or up to two less (x m64 / 2^64 > x/q - x/(q 2^64) - x/2^64 > x/q - 2), and
+// x - e q <= x never leaves 64 bits, so two conditional subtractions finish it for every q.
+__device__ __forceinline__ u64 reduce64(u64 x, u64 q, u64 m64)
+{
+    u64 r = x - mul_hi(x, m64) * q;
+    r = r >= q ? r - q : r;
+    return r >= q ? r - q : r;
+}
+
 // poly_add_negate_xq, bfv_keygen.cuh:80-93
+template <int V>
 __global__ void __launch_bounds__(kBlock)
 k_add_negate(u64* __restrict__ a, const u64* __restrict__ b, unsigned n, const BfvPrime* __restrict__ primes)
 {
     const unsigned y = blockIdx.y;
     const u64 q = primes[y].q;
-    const size_t i = (size_t)y * n + blockIdx.x * kBlock + threadIdx.x;
-    u64 ra = a[i] + b[i];
-    if (ra >= q) ra -= q;
-    ra = q - ra;
-    a[i] = ra * (ra != q);
+    const size_t i = (size_t)y * n + (size_t)(blockIdx.x * kBlock + threadIdx.x) * V;
+    u64 va[V], vb[V];
+    ldv<V>(va, a + i);
+    ldv<V>(vb, b + i);
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        u64 ra = va[v] + vb[v];
+        if (ra >= q) ra -= q;
+        ra = q - ra;
+        va[v] = ra * (ra != q);
+    }
+    stv<V>(a + i, va);
 }
 
 // keygen in the NTT domain: pk0 <- -(a_hat (.) s_hat + pk0) with pk0 holding NTT(e) on entry.  The reference forms
 // NTT(-(INTT(a_hat (.) s_hat) + e)) (bfv_keygen.cuh:131-145: barrett_batch_3param, inverseNTT_batch, poly_add_negate_xq,
 // forwardNTT_batch); the transform is linear and every step exact, so the canonical words are the same -- without the inverse
 // transform.
+template <int V>
 __global__ void __launch_bounds__(kBlock)
 k_keygen_pk0(u64* __restrict__ pk0, const u64* __restrict__ a_hat, const u64* __restrict__ s_hat, unsigned n,
              const BfvPrime* __restrict__ primes)
 {
     const unsigned y = blockIdx.y;
     const BfvPrime p = primes[y];
-    const size_t i = (size_t)y * n + blockIdx.x * kBlock + threadIdx.x;
-    u64 ra = barrett_mul(a_hat[i], s_hat[i], p.q, p.mu, p.k) + pk0[i];
-    if (ra >= p.q) ra -= p.q;
-    ra = p.q - ra;
-    pk0[i] = ra * (ra != p.q);
+    const size_t i = (size_t)y * n + (size_t)(blockIdx.x * kBlock + threadIdx.x) * V;
+    u64 va[V], vs[V], vp[V];
+    ldv<V>(va, a_hat + i);
+    ldv<V>(vs, s_hat + i);
+    ldv<V>(vp, pk0 + i);
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        u64 ra = barrett_mul(va[v], vs[v], p.q, p.mu, p.k) + vp[v];
+        if (ra >= p.q) ra -= p.q;
+        ra = p.q - ra;
+        vp[v] = ra * (ra != p.q);
+    }
+    stv<V>(pk0 + i, vp);
 }
 
-// one column i of one half h of the ciphertext: poly_add_xq on all R polynomials (note `>`, bfv_encryption.cuh:180),
-// +half on the last one (:110-124), subtract-and-scale on the others (:126-171), message term on c0 (:186-208)
+// V columns i.. of one half h of the ciphertext: poly_add_xq on all R polynomials (note `>`, bfv_encryption.cuh:180),
+// +half on the last one (:110-124), subtract-and-scale on the others (:126-171), message term on c0 (:186-208).
+// The reference's two `%` (:150 last % q_j, :204 the message term) are reduce64 -- the same words for every input; its
+// `/ t` (:203) is 0 or 1 for a message below t and a real division otherwise.
+template <int V>
 __global__ void __launch_bounds__(kBlock)
 k_encrypt_tail(u64* __restrict__ c, const u64* __restrict__ e, const u64* __restrict__ m, unsigned n, unsigned R, u64 t,
                const BfvPrime* __restrict__ primes, size_t half_stride)
 {
     // blockIdx.z: ciphertext of a batch laid out [2][count][R][n] (half_stride = count R n; one ciphertext: R n, gridDim.z = 1)
     const unsigned h = blockIdx.y;
-    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned i = (blockIdx.x * kBlock + threadIdx.x) * V;
     const unsigned r = R - 1;
     u64* ch = c + (size_t)blockIdx.z * R * n + h * half_stride;
     const u64* eh = e + (size_t)blockIdx.z * R * n + h * half_stride;
     m += (size_t)blockIdx.z * n;
     const u64 q_last = primes[r].q, half_last = q_last >> 1;
-    u64 last = ch[(size_t)r * n + i] + eh[(size_t)r * n + i];
-    if (last > q_last) last -= q_last;                         // poly_add_xq
-    last += half_last;                                         // ..._add_x2
-    if (last >= q_last) last -= q_last;
-    ch[(size_t)r * n + i] = last;
-    u64 mi = 0, fix = 0;
+    u64 last[V], el[V];
+    ldv<V>(last, ch + (size_t)r * n + i);
+    ldv<V>(el, eh + (size_t)r * n + i);
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        last[v] += el[v];
+        if (last[v] > q_last) last[v] -= q_last;               // poly_add_xq
+        last[v] += half_last;                                  // ..._add_x2
+        if (last[v] >= q_last) last[v] -= q_last;
+    }
+    stv<V>(ch + (size_t)r * n + i, last);
+    u64 mi[V] = {}, fix[V] = {};
     if (h == 0) {
-        mi = m[i];
-        fix = (mi + ((t + 1) >> 1)) / t;                       // weird_m_stuff: numerator / t
+        ldv<V>(mi, m + i);
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const u64 num = mi[v] + ((t + 1) >> 1);            // weird_m_stuff: numerator / t
+            fix[v] = num < t ? 0 : (num - t < t ? 1 : num / t);
+        }
     }
     for (unsigned j = 0; j < r; j++) {
         const BfvPrime p = primes[j];
-        u64 x = ch[(size_t)j * n + i] + eh[(size_t)j * n + i];
-        if (x > p.q) x -= p.q;                                 // poly_add_xq
-        u64 tmp = last % p.q;                                  // ..._loop_xq
-        if (tmp < p.half_last_mod_q) tmp += p.q;
-        tmp -= p.half_last_mod_q;
-        if (x < tmp) x += p.q;
-        x -= tmp;
-        x = barrett_mul(x, p.inv_q_last_mod_q, p.q, p.mu, p.k);
-        if (h == 0) x = (x + (mi * p.q_div_t + fix)) % p.q;    // weird_m_stuff
-        ch[(size_t)j * n + i] = x;
+        u64 x[V], ex[V];
+        ldv<V>(x, ch + (size_t)j * n + i);
+        ldv<V>(ex, eh + (size_t)j * n + i);
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            x[v] += ex[v];
+            if (x[v] > p.q) x[v] -= p.q;                       // poly_add_xq
+            u64 tmp = reduce64(last[v], p.q, p.m64);           // ..._loop_xq
+            if (tmp < p.half_last_mod_q) tmp += p.q;
+            tmp -= p.half_last_mod_q;
+            if (x[v] < tmp) x[v] += p.q;
+            x[v] -= tmp;
+            x[v] = barrett_mul(x[v], p.inv_q_last_mod_q, p.q, p.mu, p.k);
+            if (h == 0) x[v] = reduce64(x[v] + (mi[v] * p.q_div_t + fix[v]), p.q, p.m64);    // weird_m_stuff
+        }
+        stv<V>(ch + (size_t)j * n + i, x);
     }
 }
 
 // c1[i] = ((c1[i] + c0[i], `>`) * prod_t_gamma) * inv_punctured_q, bfv_decryption.cuh:13-57
+template <int V>
 __global__ void __launch_bounds__(kBlock)
 k_decrypt_scale(u64* __restrict__ c, unsigned n, unsigned R, const BfvPrime* __restrict__ primes, size_t half_stride)
 {
     const unsigned y = blockIdx.y;
     const BfvPrime p = primes[y];
-    const size_t i = (size_t)y * n + blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = (size_t)y * n + (size_t)(blockIdx.x * kBlock + threadIdx.x) * V;
     c += (size_t)blockIdx.z * R * n;
     u64* c1 = c + half_stride;
-    u64 ra = c1[i] + c[i];
-    if (ra > p.q) ra -= p.q;
-    ra = barrett_mul(ra, p.prod_t_gamma_mod_q, p.q, p.mu, p.k);
-    ra = barrett_mul(ra, p.inv_punctured_q, p.q, p.mu, p.k);
-    c1[i] = ra;
+    u64 a1[V], a0[V];
+    ldv<V>(a1, c1 + i);
+    ldv<V>(a0, c + i);
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        u64 ra = a1[v] + a0[v];
+        if (ra > p.q) ra -= p.q;
+        ra = barrett_mul(ra, p.prod_t_gamma_mod_q, p.q, p.mu, p.k);
+        a1[v] = barrett_mul(ra, p.inv_punctured_q, p.q, p.mu, p.k);
+    }
+    stv<V>(c1 + i, a1);
 }
 
-// poly_arithmetic.cuh:221-268, :128-142, barrett_int (:100-126) per column k
+// poly_arithmetic.cuh:221-268, :128-142, barrett_int (:100-126) per column k.  The running sum's `% gamma` (:252) takes an
+// accumulator below gamma and a product below 2^64: reduce64; the final `% gamma` (:262) then finds a reduced value.
+template <int V>
 __global__ void __launch_bounds__(kBlock)
 k_decrypt_round(u64* __restrict__ c, unsigned n, unsigned R, u64 t, u64 gamma, u64 mu_gamma, unsigned gamma_bits, u64 gamma_div_2,
-                u64 neg_inv_t, u64 neg_inv_gamma, const u64* __restrict__ bcm, size_t half_stride)
+                u64 neg_inv_t, u64 neg_inv_gamma, const u64* __restrict__ bcm, size_t half_stride, u64 m64_gamma)
 {
-    const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned k = (blockIdx.x * kBlock + threadIdx.x) * V;
     const unsigned r = R - 1;
     c += (size_t)blockIdx.z * R * n;
     const u64* c1 = c + half_stride;
     const unsigned mask32 = (unsigned)(t - 1);                 // `unsigned mask = t - 1`
-    u64 acc_t = 0, acc_g = 0;
+    const u64 mask = t - 1;                                    // dec_round_kernel
+    u64 acc_t[V] = {}, acc_g[V] = {};
     for (unsigned i = 0; i < r; i++) {
-        const u64 v = c1[k + (size_t)i * n];
-        acc_t += (v * bcm[i]) & mask32;                                            // fast_convert_array_kernel_t
-        const u64 tg = barrett_mul(v, bcm[i + r], gamma, mu_gamma, gamma_bits);   // fast_convert_array_kernel_gamma
-        acc_g = (acc_g + tg) % gamma;
+        u64 val[V];
+        ldv<V>(val, c1 + k + (size_t)i * n);
+        const u64 bt = bcm[i], bg = bcm[i + r];
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            acc_t[v] += (val[v] * bt) & mask32;                                          // fast_convert_array_kernel_t
+            const u64 tg = barrett_mul(val[v], bg, gamma, mu_gamma, gamma_bits);         // fast_convert_array_kernel_gamma
+            acc_g[v] = reduce64(acc_g[v] + tg, gamma, m64_gamma);
+        }
     }
-    u64 x0 = acc_t & mask32;
-    u64 x1 = acc_g % gamma;
-    x0 = (x0 * neg_inv_t) & mask32;                                                // poly_mul_int_t -> mod_t
-    x1 = barrett_mul(x1, neg_inv_gamma, gamma, mu_gamma, gamma_bits);             // poly_mul_int -> barrett_int
-    c[k] = x0;
-    c[k + n] = x1;
-    const u64 mask = t - 1;                                                        // dec_round_kernel
-    u64 res;
-    if (x1 > gamma_div_2) res = (x0 + (gamma - x1)) & mask;
-    else res = (x0 - x1) & mask;
-    c[k + (size_t)n * (r - 1)] = res;
+    u64 x0[V], x1[V], res[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        x0[v] = acc_t[v] & mask32;
+        x1[v] = acc_g[v];                                                                // (acc_g % gamma: already reduced)
+        x0[v] = (x0[v] * neg_inv_t) & mask32;                                            // poly_mul_int_t -> mod_t
+        x1[v] = barrett_mul(x1[v], neg_inv_gamma, gamma, mu_gamma, gamma_bits);          // poly_mul_int -> barrett_int
+        if (x1[v] > gamma_div_2) res[v] = (x0[v] + (gamma - x1[v])) & mask;
+        else res[v] = (x0[v] - x1[v]) & mask;
+    }
+    stv<V>(c + k, x0);                     // (in this order: for R <= 3 the three destinations coincide pairwise, as in the reference)
+    stv<V>(c + k + n, x1);
+    stv<V>(c + k + (size_t)n * (r - 1), res);
 }
+
+template <class... P>
+__host__ bool aligned16(P... p) { return ((reinterpret_cast<uintptr_t>(p) | ...) & 15u) == 0; }
 
 // ---- samplers --------------------------------------------------------------------------------
 
@@ -246,34 +332,44 @@ hipError_t bfv_sample_encrypt(const BfvParams& p, const BfvDevice& d, const unsi
 
 hipError_t bfv_add_negate(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* e, hipStream_t s)
 {
-    k_add_negate<<<dim3(p.n / kBlock, p.R), kBlock, 0, s>>>(pk0, e, p.n, d.d_prime);
+    if (aligned16(pk0, e)) k_add_negate<2><<<dim3(p.n / (2 * kBlock), p.R), kBlock, 0, s>>>(pk0, e, p.n, d.d_prime);
+    else k_add_negate<1><<<dim3(p.n / kBlock, p.R), kBlock, 0, s>>>(pk0, e, p.n, d.d_prime);
     return hipGetLastError();
 }
 
 hipError_t bfv_keygen_pk0(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* a_hat, const u64* s_hat, hipStream_t s)
 {
-    k_keygen_pk0<<<dim3(p.n / kBlock, p.R), kBlock, 0, s>>>(pk0, a_hat, s_hat, p.n, d.d_prime);
+    if (aligned16(pk0, a_hat, s_hat)) k_keygen_pk0<2><<<dim3(p.n / (2 * kBlock), p.R), kBlock, 0, s>>>(pk0, a_hat, s_hat, p.n, d.d_prime);
+    else k_keygen_pk0<1><<<dim3(p.n / kBlock, p.R), kBlock, 0, s>>>(pk0, a_hat, s_hat, p.n, d.d_prime);
     return hipGetLastError();
 }
 
 // count > 1: a batch of ciphertexts laid out [2][count][R][n] (all first halves, then all second halves)
 hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s, unsigned count)
 {
-    k_encrypt_tail<<<dim3(p.n / kBlock, 2, count), kBlock, 0, s>>>(c, e, m, p.n, p.R, p.t, d.d_prime, (size_t)count * p.R * p.n);
+    const size_t hs = (size_t)count * p.R * p.n;
+    if (aligned16(c, e, m)) k_encrypt_tail<2><<<dim3(p.n / (2 * kBlock), 2, count), kBlock, 0, s>>>(c, e, m, p.n, p.R, p.t, d.d_prime, hs);
+    else k_encrypt_tail<1><<<dim3(p.n / kBlock, 2, count), kBlock, 0, s>>>(c, e, m, p.n, p.R, p.t, d.d_prime, hs);
     return hipGetLastError();
 }
 
 hipError_t bfv_decrypt_scale(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count)
 {
-    k_decrypt_scale<<<dim3(p.n / kBlock, p.r, count), kBlock, 0, s>>>(c, p.n, p.R, d.d_prime, (size_t)count * p.R * p.n);
+    const size_t hs = (size_t)count * p.R * p.n;
+    if (aligned16(c)) k_decrypt_scale<2><<<dim3(p.n / (2 * kBlock), p.r, count), kBlock, 0, s>>>(c, p.n, p.R, d.d_prime, hs);
+    else k_decrypt_scale<1><<<dim3(p.n / kBlock, p.r, count), kBlock, 0, s>>>(c, p.n, p.R, d.d_prime, hs);
     return hipGetLastError();
 }
 
 hipError_t bfv_decrypt_round(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count)
 {
-    k_decrypt_round<<<dim3(p.n / kBlock, 1, count), kBlock, 0, s>>>(c, p.n, p.R, p.t, p.gamma, p.mu_gamma, p.gamma_bits, p.gamma_div_2,
-                                                                    p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change,
-                                                                    (size_t)count * p.R * p.n);
+    const size_t hs = (size_t)count * p.R * p.n;
+    if (aligned16(c))
+        k_decrypt_round<2><<<dim3(p.n / (2 * kBlock), 1, count), kBlock, 0, s>>>(c, p.n, p.R, p.t, p.gamma, p.mu_gamma, p.gamma_bits, p.gamma_div_2,
+                                                                              p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change, hs, p.m64_gamma);
+    else
+        k_decrypt_round<1><<<dim3(p.n / kBlock, 1, count), kBlock, 0, s>>>(c, p.n, p.R, p.t, p.gamma, p.mu_gamma, p.gamma_bits, p.gamma_div_2,
+                                                                          p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change, hs, p.m64_gamma);
     return hipGetLastError();
 }
 

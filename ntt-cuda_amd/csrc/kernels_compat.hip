@@ -351,6 +351,18 @@ hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsi
     return hipGetLastError();
 }
 
+static __global__ void guard_invert_kernel(unsigned* __restrict__ guard)
+{
+    const unsigned e = guard[0];
+    guard[2] = e;
+    guard[3] = guard[0] != guard[1] ? e : ~e;
+}
+hipError_t compat_guard_invert(unsigned* d_guard, hipStream_t s)
+{
+    guard_invert_kernel<<<1, 1, 0, s>>>(d_guard);
+    return hipGetLastError();
+}
+
 hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s)
 {
     tables_check_kernel<<<128, kBlock, 0, s>>>(d_x, d_y, n, count, d_guard, epoch);
@@ -363,7 +375,9 @@ hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsig
 // adds q where a < b and NEVER subtracts b -- mirrored literally), poly_negate (:334-338), mod_t (:128-142:
 // the low 64 bits of a b, masked with t - 1 held in a 32-bit register).  One streaming kernel, 16 bytes per lane, grid-stride.
 namespace {
-template <int OP>
+// VEC: 16 bytes per lane (both pointers 16-byte aligned); otherwise one word per lane -- the reference's kernels take any pointer to
+// unsigned long long, and its wrappers return void: a call on a + odd_offset must transform, not be refused.
+template <int OP, bool VEC>
 __global__ void __launch_bounds__(256) k_elementwise(u64* __restrict__ a, const u64* __restrict__ b, u64 scalar, u64 q, size_t count)
 {
     auto f = [&](u64 x, u64 y) -> u64 {
@@ -381,37 +395,49 @@ __global__ void __launch_bounds__(256) k_elementwise(u64* __restrict__ a, const 
         }
     };
     constexpr bool VEC_B = (OP == kEwAdd || OP == kEwSub);
-    const size_t pairs = count / 2, stride = (size_t)gridDim.x * 256;
-    ulonglong2* a2 = reinterpret_cast<ulonglong2*>(a);
-    const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride) {
-        ulonglong2 x = a2[i];
-        ulonglong2 y;
-        if constexpr (VEC_B) y = b2[i];
-        else y = make_ulonglong2(scalar, scalar);
-        x.x = f(x.x, y.x);
-        x.y = f(x.y, y.y);
-        a2[i] = x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if constexpr (VEC) {
+        const size_t pairs = count / 2;
+        ulonglong2* a2 = reinterpret_cast<ulonglong2*>(a);
+        const ulonglong2* b2 = reinterpret_cast<const ulonglong2*>(b);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride) {
+            ulonglong2 x = a2[i];
+            ulonglong2 y;
+            if constexpr (VEC_B) y = b2[i];
+            else y = make_ulonglong2(scalar, scalar);
+            x.x = f(x.x, y.x);
+            x.y = f(x.y, y.y);
+            a2[i] = x;
+        }
+        if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) a[count - 1] = f(a[count - 1], VEC_B ? b[count - 1] : scalar);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) a[i] = f(a[i], VEC_B ? b[i] : scalar);
     }
-    if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) a[count - 1] = f(a[count - 1], VEC_B ? b[count - 1] : scalar);
 }
 }  // namespace
 
 hipError_t compat_elementwise(int op, u64* d_a, const u64* d_b, u64 scalar, u64 q, size_t count, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
-    size_t blocks = (count / 2 + 255) / 256;
+    const bool vec = ((reinterpret_cast<uintptr_t>(d_a) | reinterpret_cast<uintptr_t>(d_b)) & 15u) == 0;      // (a null d_b counts as aligned)
+    size_t blocks = ((vec ? count / 2 : count) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     const unsigned g = (unsigned)blocks;
+#define MI355NTT_EW(OP, B, SC)                                                        \
+    do {                                                                              \
+        if (vec) k_elementwise<OP, true><<<g, 256, 0, s>>>(d_a, B, SC, q, count);     \
+        else k_elementwise<OP, false><<<g, 256, 0, s>>>(d_a, B, SC, q, count);        \
+    } while (0)
     switch (op) {
-    case kEwAdd: k_elementwise<kEwAdd><<<g, 256, 0, s>>>(d_a, d_b, 0, q, count); break;
-    case kEwAddInteger: k_elementwise<kEwAddInteger><<<g, 256, 0, s>>>(d_a, nullptr, scalar, q, count); break;
-    case kEwSub: k_elementwise<kEwSub><<<g, 256, 0, s>>>(d_a, d_b, 0, q, count); break;
-    case kEwNegate: k_elementwise<kEwNegate><<<g, 256, 0, s>>>(d_a, nullptr, 0, q, count); break;
-    case kEwMulIntT: k_elementwise<kEwMulIntT><<<g, 256, 0, s>>>(d_a, nullptr, scalar, q, count); break;
+    case kEwAdd: MI355NTT_EW(kEwAdd, d_b, 0); break;
+    case kEwAddInteger: MI355NTT_EW(kEwAddInteger, nullptr, scalar); break;
+    case kEwSub: MI355NTT_EW(kEwSub, d_b, 0); break;
+    case kEwNegate: MI355NTT_EW(kEwNegate, nullptr, 0); break;
+    case kEwMulIntT: MI355NTT_EW(kEwMulIntT, nullptr, scalar); break;
     default: return hipErrorInvalidValue;
     }
+#undef MI355NTT_EW
     return hipGetLastError();
 }
 

@@ -33,6 +33,9 @@ __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restri
     static_for<32>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int r = PAIR16 ? ((i >> 1) | ((i & 1) << 4)) : i;
+#ifdef MI355NTT_ABLATE_LOADK     // timing experiments only (round 5, bound of pre-landing): the first K loads in issue order cost nothing
+        if constexpr (i < MI355NTT_ABLATE_LOADK) { v[r] = (u64)t * 0x9E3779B97F4A7C15ULL + r; return; }
+#endif
         v[r] = buf_load_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u);
         if constexpr (PAIR16) __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise re-sorts the loads by register)
     });
@@ -53,6 +56,13 @@ __device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restr
     for (int r = 0; r < 32; r++) acc ^= v[r];
     if (acc == 0x123456789ULL) poly[t] = acc;
     return;
+#endif
+#ifdef MI355NTT_ABLATE_STORES     // timing experiments only: no result stores (results are wrong)
+    { u64 acc = 0;
+#pragma unroll
+      for (int r = 0; r < 32; r++) acc ^= v[r];
+      if (acc == 0x123456789ULL) poly[t] = acc;
+      return; }
 #endif
     const BufRsrc rs = make_rsrc(poly, Geo<LOGN>::N * 8u);
 #pragma unroll
@@ -263,6 +273,11 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 #ifndef MI355NTT_INV_DESCENDING
 #define MI355NTT_INV_DESCENDING 1
 #endif
+// k_inverse15: the next polynomial's first column half pre-landed in the wave slices by LDS-direct loads issued behind the
+// workgroup-wide exchange (wave_preland_rows_half, ntt_core.cuh)
+#ifndef MI355NTT_INV_PRELAND
+#define MI355NTT_INV_PRELAND 1
+#endif
 #define MI355NTT_INV_POS(y) (MI355NTT_INV_DESCENDING ? num - 1u - (y) : (y))
 // timing experiments only (tools/kbench.hip): fold the polynomial index so the batch stays in the MALL or in L2
 #ifndef MI355NTT_POLY_SLOT
@@ -403,6 +418,9 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         MI355NTT_STAMPV(5, 4);
+#ifdef MI355NTT_PRIO_FMEM
+        MI355NTT_SETPRIO(MI355NTT_PRIO_FMEM);
+#endif
         // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic instead of a VGPR kept live across the loop)
         wave_store_rows(v, lds + wave_s * WAVE_SLICE_WORDS, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
         MI355NTT_STAMPV(-1, 5);
@@ -613,13 +631,36 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         MI355NTT_STAMP2(it, 3);
         exchange<LOGN, 5, 10>(v, lds, fresh_t());
         MI355NTT_STAMP2(it, 4);
+#if MI355NTT_INV_PRELAND
+        // (the exchange ends with a barrier: every slice is dead until this wave's own row staging) the next polynomial's first
+        // column half starts its way from memory now and lands in the slice during the last round
+        if (ynext < num)
+            wave_preland_rows_half<0>(slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u));
+#endif
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
         gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
         MI355NTT_STAMP2(it, 5);
+#ifdef MI355NTT_PRIO_IMEM
+        MI355NTT_SETPRIO(MI355NTT_PRIO_IMEM);
+#endif
         store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
+#if MI355NTT_INV_PRELAND
+        if (ynext < num) {
+            // the eight LDS-direct loads are older than the 32 result stores: counted wait (hipcc does not order an LDS read behind
+            // the LDS-direct load that fills it; loads, stores and LDS-direct loads retire in issue order on one counter)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            u64 h[16];
+            wave_read_prelanded_half(h, slice);
+            static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
+            wave_load_rows_half<1>(h, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+            static_for<16>([&](auto rc) { v[16 + decltype(rc)::value] = h[decltype(rc)::value]; });
+        }
+#else
         if (ynext < num)
             wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+#endif
         MI355NTT_STAMP2(it, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
         it++;

@@ -24,7 +24,7 @@
 // ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
 // CXXFLAGS then stops the compilation instead of shipping a different kernel.
 #ifndef MI355NTT_LAB
-#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || \
+#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || \
     defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
     defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
     defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \
@@ -658,6 +658,9 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
     if (acc == 0x123456789ULL) slice[0] = acc;
     return;
 #endif
+#ifdef MI355NTT_ABLATE_STORES        // timing experiments only: the LDS staging stays, the global stores go
+#define MI355NTT_ROWSTORE_SKIP 1
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
@@ -675,6 +678,9 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
             const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz_store(8 * k + rr)) << 4));
             v4u32 x;
             x.x = lo32(pr.x); x.y = hi32(pr.x); x.z = lo32(pr.y); x.w = hi32(pr.y);
+#ifdef MI355NTT_ROWSTORE_SKIP
+            if (x.x == 0x12345u && x.w == 0x54321u)
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, MI355NTT_STREAM_AUX_ST);
         });
         wave_lds_fence();
@@ -691,6 +697,9 @@ __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, 
     v4u32 x[8];
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
+#ifdef MI355NTT_ABLATE_LOADK     // timing experiments only (round 5, bound of pre-landing): the first K/2 of the 16 row loads cost nothing
+        if constexpr (8 * CH + k < MI355NTT_ABLATE_LOADK / 2) { x[k] = v4u32{lane, sw, lane, sw}; return; }
+#endif
         x[k] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + CH * 128u, MI355NTT_STREAM_AUX_LD);
     });
     static_for<8>([&](auto kc) {
@@ -698,6 +707,39 @@ __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, 
         *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4)) = x[k];
     });
     wave_lds_fence();
+    static_for<8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + lane * 128 + ((m ^ row_swz(lane)) << 4));
+        out[2 * m] = pr.x;
+        out[2 * m + 1] = pr.y;
+    });
+    wave_lds_fence();
+}
+
+// Pre-landing (round 5): column half CH of this wave's rows requested by LDS-direct loads -- global memory -> LDS without a VGPR in
+// between, so the request can go out while the registers still hold the previous polynomial (k_inverse15: right behind the
+// workgroup-wide exchange, when the slices are dead and the last round reads its twiddles through the scalar cache: nothing else of
+// this wave sits in the vector-memory queue until the result stores).  Lane L of instruction k lands at slice + 1024 k + 16 L, i.e.
+// row 8 k + (L >> 3), slot L & 7 of the staging layout of wave_load_rows_half; the swizzle moves to the global side: the lane fetches
+// piece slot ^ row_swz(row) of its row (still eight whole 128-byte lines per instruction).
+typedef __attribute__((address_space(3))) void* LdsVoidPtr;
+template <int CH>
+__device__ __forceinline__ void wave_preland_rows_half(u64* slice, BufRsrc src)
+{
+    const unsigned lane = fresh_lane_id();
+    const unsigned sw = lane & 7, rr = lane >> 3;
+    const unsigned voff_even = rr * 256u + ((sw ^ (rr >> 1)) << 4);       // row_swz(8 k + rr) = 4 (k & 1) | (rr >> 1)
+    const unsigned voff_odd = voff_even ^ 64u;
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (LdsVoidPtr)(slice + k * 128), 16, (k & 1) ? voff_odd : voff_even, k * 2048u + CH * 128u, 0, MI355NTT_STREAM_AUX_LD);
+    });
+}
+// (the caller has waited for the eight LDS-direct loads with a counted s_waitcnt vmcnt)
+__device__ __forceinline__ void wave_read_prelanded_half(u64 (&out)[16], const u64* slice)
+{
+    const unsigned lane = fresh_lane_id();
+    const char* base = reinterpret_cast<const char*>(slice);
     static_for<8>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + lane * 128 + ((m ^ row_swz(lane)) << 4));

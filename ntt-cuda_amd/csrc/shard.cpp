@@ -66,6 +66,21 @@ static int run_op(const mi355ntt_ctx* c, int op, mi355ntt_u64* d, const mi355ntt
     }
 }
 
+// Error path of the two fork / join calls: whatever was enqueued on the lanes' streams before the failure is allowed to finish (host
+// synchronisation -- this is not the fast path), so that an error code never comes back while another device still writes the
+// caller's buffers.
+static void drain_lanes(mi355ntt_shards* s)
+{
+    for (Lane& l : s->lane) {
+        DeviceScope scope(l.device);
+        if (scope.err != hipSuccess) continue;
+        if (l.s_in) (void)hipStreamSynchronize(l.s_in);
+        if (l.s_cmp) (void)hipStreamSynchronize(l.s_cmp);
+        if (l.s_out) (void)hipStreamSynchronize(l.s_out);
+    }
+    (void)hipGetLastError();
+}
+
 // pieces of a shard of `count` polynomials: at most `chunks`, at most piece_polys each, starts at multiples of `division`
 static void piece_plan(unsigned count, unsigned division, unsigned chunks, unsigned piece_polys, std::vector<std::pair<unsigned, unsigned>>* out)
 {
@@ -201,29 +216,37 @@ int mi355ntt_shards_transform(mi355ntt_shards* s, int op, mi355ntt_u64* const* d
                               unsigned division, mi355ntt_stream stream)
 {
     if (!s || !d_shard || division == 0 || division > s->num_primes) return MI355NTT_EINVAL;
+    if (op != MI355NTT_OP_FORWARD && op != MI355NTT_OP_INVERSE && op != MI355NTT_OP_FORWARD_INVERSE && op != MI355NTT_OP_POLYMUL) return MI355NTT_EINVAL;
     if (op == MI355NTT_OP_POLYMUL && !d_bhat_shard) return MI355NTT_EINVAL;
-    {
-        DeviceScope scope(s->lane[0].device);
-        HIP_TRY(scope.err);
-        HIP_TRY(hipEventRecord(s->ev_start, (hipStream_t)stream));
-    }
+    // every argument is checked BEFORE the fork: nothing is in flight when an argument error is reported
     for (unsigned r = 0; r < s->world; r++) {
         unsigned first = 0, count = 0;
         RC_TRY(mi355ntt_shard_range(num, division, r, s->world, &first, &count));
-        Lane& l = s->lane[r];
-        DeviceScope scope(l.device);
-        HIP_TRY(scope.err);
-        HIP_TRY(hipStreamWaitEvent(l.s_cmp, s->ev_start, 0));
-        if (count) {
-            if (!d_shard[r]) return MI355NTT_EINVAL;
-            RC_TRY(run_op(l.ctx, op, d_shard[r], d_bhat_shard ? d_bhat_shard[r] : nullptr, count, division, l.s_cmp));
-        }
-        HIP_TRY(hipEventRecord(l.ev_done, l.s_cmp));
+        if (count && (!d_shard[r] || (op == MI355NTT_OP_POLYMUL && !d_bhat_shard[r]))) return MI355NTT_EINVAL;
     }
-    DeviceScope scope(s->lane[0].device);
-    HIP_TRY(scope.err);
-    for (unsigned r = 0; r < s->world; r++) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->lane[r].ev_done, 0));
-    return MI355NTT_OK;
+    const int rc = [&]() -> int {
+        {
+            DeviceScope scope(s->lane[0].device);
+            HIP_TRY(scope.err);
+            HIP_TRY(hipEventRecord(s->ev_start, (hipStream_t)stream));
+        }
+        for (unsigned r = 0; r < s->world; r++) {
+            unsigned first = 0, count = 0;
+            RC_TRY(mi355ntt_shard_range(num, division, r, s->world, &first, &count));
+            Lane& l = s->lane[r];
+            DeviceScope scope(l.device);
+            HIP_TRY(scope.err);
+            HIP_TRY(hipStreamWaitEvent(l.s_cmp, s->ev_start, 0));
+            if (count) RC_TRY(run_op(l.ctx, op, d_shard[r], d_bhat_shard ? d_bhat_shard[r] : nullptr, count, division, l.s_cmp));
+            HIP_TRY(hipEventRecord(l.ev_done, l.s_cmp));
+        }
+        DeviceScope scope(s->lane[0].device);
+        HIP_TRY(scope.err);
+        for (unsigned r = 0; r < s->world; r++) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->lane[r].ev_done, 0));
+        return MI355NTT_OK;
+    }();
+    if (rc != MI355NTT_OK) drain_lanes(s);      // a HIP failure half-way: no lane may still be writing the caller's buffers when the error is reported
+    return rc;
 }
 
 /* Root-resident batch (the end-to-end report of SURVEY.md 8(e)): d_full [num][n] lives on lane 0's device.  Lane r > 0 receives its
@@ -237,49 +260,53 @@ int mi355ntt_shards_scatter_transform_gather(mi355ntt_shards* s, int op, mi355nt
     if (!s || !d_full || division == 0 || division > s->num_primes || chunks == 0) return MI355NTT_EINVAL;
     if (op != MI355NTT_OP_FORWARD && op != MI355NTT_OP_INVERSE && op != MI355NTT_OP_FORWARD_INVERSE) return MI355NTT_EINVAL;
     if (s->world > 1 && s->piece_polys < division) return MI355NTT_EINVAL;       // (created without staging)
-    const int root = s->lane[0].device;
-    const size_t poly_bytes = (size_t)s->n * sizeof(mi355ntt_u64);
-    {
+    const int rc = [&]() -> int {
+        const int root = s->lane[0].device;
+        const size_t poly_bytes = (size_t)s->n * sizeof(mi355ntt_u64);
+        {
+            DeviceScope scope(root);
+            HIP_TRY(scope.err);
+            HIP_TRY(hipEventRecord(s->ev_start, (hipStream_t)stream));
+        }
+        std::vector<std::pair<unsigned, unsigned>> pieces;
+        for (unsigned r = 0; r < s->world; r++) {
+            unsigned first = 0, count = 0;
+            RC_TRY(mi355ntt_shard_range(num, division, r, s->world, &first, &count));
+            Lane& l = s->lane[r];
+            DeviceScope scope(l.device);
+            HIP_TRY(scope.err);
+            if (r == 0) {                                                       // the root's shard: in place
+                HIP_TRY(hipStreamWaitEvent(l.s_cmp, s->ev_start, 0));
+                if (count) RC_TRY(run_op(l.ctx, op, d_full + (size_t)first * s->n, nullptr, count, division, l.s_cmp));
+                HIP_TRY(hipEventRecord(l.ev_done, l.s_cmp));
+                continue;
+            }
+            HIP_TRY(hipStreamWaitEvent(l.s_in, s->ev_start, 0));
+            piece_plan(count, division, chunks, s->piece_polys, &pieces);
+            for (size_t k = 0; k < pieces.size(); k++) {
+                const int b = (int)(k % kRing);
+                mi355ntt_u64* src = d_full + (size_t)(first + pieces[k].first) * s->n;
+                const size_t bytes = (size_t)pieces[k].second * poly_bytes;
+                HIP_TRY(hipStreamWaitEvent(l.s_in, l.ev_out[b], 0));      // the buffer's previous piece (of this call or of an earlier one) has left; a never-recorded event counts as complete
+                HIP_TRY(hipMemcpyPeerAsync(l.stage[b], l.device, src, root, bytes, l.s_in));
+                HIP_TRY(hipEventRecord(l.ev_in[b], l.s_in));
+                HIP_TRY(hipStreamWaitEvent(l.s_cmp, l.ev_in[b], 0));
+                RC_TRY(run_op(l.ctx, op, l.stage[b], nullptr, pieces[k].second, division, l.s_cmp));
+                HIP_TRY(hipEventRecord(l.ev_cmp[b], l.s_cmp));
+                HIP_TRY(hipStreamWaitEvent(l.s_out, l.ev_cmp[b], 0));
+                HIP_TRY(hipMemcpyPeerAsync(src, root, l.stage[b], l.device, bytes, l.s_out));
+                HIP_TRY(hipEventRecord(l.ev_out[b], l.s_out));
+            }
+            if (pieces.empty()) HIP_TRY(hipStreamWaitEvent(l.s_out, s->ev_start, 0));
+            HIP_TRY(hipEventRecord(l.ev_done, l.s_out));                       // (s_out is in order: behind the last piece's return)
+        }
         DeviceScope scope(root);
         HIP_TRY(scope.err);
-        HIP_TRY(hipEventRecord(s->ev_start, (hipStream_t)stream));
-    }
-    std::vector<std::pair<unsigned, unsigned>> pieces;
-    for (unsigned r = 0; r < s->world; r++) {
-        unsigned first = 0, count = 0;
-        RC_TRY(mi355ntt_shard_range(num, division, r, s->world, &first, &count));
-        Lane& l = s->lane[r];
-        DeviceScope scope(l.device);
-        HIP_TRY(scope.err);
-        if (r == 0) {                                                       // the root's shard: in place
-            HIP_TRY(hipStreamWaitEvent(l.s_cmp, s->ev_start, 0));
-            if (count) RC_TRY(run_op(l.ctx, op, d_full + (size_t)first * s->n, nullptr, count, division, l.s_cmp));
-            HIP_TRY(hipEventRecord(l.ev_done, l.s_cmp));
-            continue;
-        }
-        HIP_TRY(hipStreamWaitEvent(l.s_in, s->ev_start, 0));
-        piece_plan(count, division, chunks, s->piece_polys, &pieces);
-        for (size_t k = 0; k < pieces.size(); k++) {
-            const int b = (int)(k % kRing);
-            mi355ntt_u64* src = d_full + (size_t)(first + pieces[k].first) * s->n;
-            const size_t bytes = (size_t)pieces[k].second * poly_bytes;
-            HIP_TRY(hipStreamWaitEvent(l.s_in, l.ev_out[b], 0));      // the buffer's previous piece (of this call or of an earlier one) has left; a never-recorded event counts as complete
-            HIP_TRY(hipMemcpyPeerAsync(l.stage[b], l.device, src, root, bytes, l.s_in));
-            HIP_TRY(hipEventRecord(l.ev_in[b], l.s_in));
-            HIP_TRY(hipStreamWaitEvent(l.s_cmp, l.ev_in[b], 0));
-            RC_TRY(run_op(l.ctx, op, l.stage[b], nullptr, pieces[k].second, division, l.s_cmp));
-            HIP_TRY(hipEventRecord(l.ev_cmp[b], l.s_cmp));
-            HIP_TRY(hipStreamWaitEvent(l.s_out, l.ev_cmp[b], 0));
-            HIP_TRY(hipMemcpyPeerAsync(src, root, l.stage[b], l.device, bytes, l.s_out));
-            HIP_TRY(hipEventRecord(l.ev_out[b], l.s_out));
-        }
-        if (pieces.empty()) HIP_TRY(hipStreamWaitEvent(l.s_out, s->ev_start, 0));
-        HIP_TRY(hipEventRecord(l.ev_done, l.s_out));                       // (s_out is in order: behind the last piece's return)
-    }
-    DeviceScope scope(root);
-    HIP_TRY(scope.err);
-    for (unsigned r = 0; r < s->world; r++) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->lane[r].ev_done, 0));
-    return MI355NTT_OK;
+        for (unsigned r = 0; r < s->world; r++) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->lane[r].ev_done, 0));
+        return MI355NTT_OK;
+    }();
+    if (rc != MI355NTT_OK) drain_lanes(s);      // (see mi355ntt_shards_transform)
+    return rc;
 }
 
 }  // extern "C"

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "mi355ntt_ctx_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, ctypes.c_int]),
     "mi355ntt_ctx_create_ex": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, ctypes.c_int, ctypes.c_uint]),
     "mi355ntt_ctx_uses_literal_kernels": (ctypes.c_int, [vp]),
+    "mi355ntt_ctx_kernel_class": (ctypes.c_int, [vp]),
     "mi355ntt_bfv_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_uint, ctypes.c_uint, u64p, u64p, u64, u64, ctypes.c_int, ctypes.c_uint]),
     "mi355ntt_bfv_destroy": (ctypes.c_int, [vp]),
     "mi355ntt_bfv_ntt": (vp, [vp]),
@@ -309,6 +310,12 @@ class NTTContext:
     @property
     def uses_literal_kernels(self):
         return bool(lib().mi355ntt_ctx_uses_literal_kernels(self._h))
+
+    @property
+    def kernel_class(self):
+        """(headroom class 2..6, near-2^k) the throughput kernels were selected by (mi355ntt_ctx_kernel_class)"""
+        v = lib().mi355ntt_ctx_kernel_class(self._h)
+        return v & 15, bool(v & 16)
 
     @property
     def literal_routing(self):

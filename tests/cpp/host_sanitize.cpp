@@ -93,7 +93,8 @@ int main()
     CHECK(mi355ntt_forward_batch_raw(nullptr, 32768, nullptr, 1, 1, qs, &mu60, &bits60, nullptr) == MI355NTT_EINVAL);
     CHECK(mi355ntt_barrett_raw(nullptr, nullptr, nullptr, 32768, 1, 1, qs, &mu60, &bits60, nullptr) == MI355NTT_EINVAL);
     CHECK(mi355ntt_poly_add_raw(nullptr, nullptr, 16, nullptr, 17) == MI355NTT_EINVAL);
-    CHECK(mi355ntt_poly_negate_raw((u64*)8, 16, nullptr, 17) == MI355NTT_EINVAL);
+    CHECK(mi355ntt_poly_negate_raw((u64*)4, 16, nullptr, 17) == MI355NTT_EINVAL);      // (not a word boundary; word-aligned pointers are accepted)
+    CHECK(mi355ntt_ctx_kernel_class(nullptr) == MI355NTT_EINVAL);
     CHECK(mi355ntt_forward30_raw(nullptr, 2048, nullptr, 12931073, 21767333, 24, nullptr) == MI355NTT_EINVAL);
     CHECK(mi355ntt_raw_uses_fast_kernels(32768, nullptr, 0, 1, qs, &mu60, &bits60) == 0);
     CHECK(mi355ntt_raw_cache_clear() == MI355NTT_OK);

@@ -181,7 +181,7 @@ def test_throughput_kernels_use_no_scratch(kernel_compiles):
 
 
 def test_valu_ceiling_profile_matches_shipped_kernels(n15_compile):
-    """profiles/valu_ceiling_r04.json (the VALU ceiling bench.py prints beside the HBM roofline) is recomputed from the shipped
+    """profiles/valu_ceiling_r05.json (the VALU ceiling bench.py prints beside the HBM roofline) is recomputed from the shipped
     sources: instruction counts of the three polynomial loops exactly, issue cycles to 1e-6.  A kernel change without
     `python3 tools/valu_ceiling.py` in the same commit fails here (round 3 shipped a stale k_polymul15 entry)."""
     _, asm = n15_compile

@@ -236,7 +236,31 @@ def test_elementwise_wrappers_match_the_reference_arithmetic(native, oracle, gpu
     assert np.array_equal(native.to_host(d), oracle.poly_negate(a[:1029], 1 << 50))
     L = native.lib()
     assert L.mi355ntt_poly_add_raw(None, None, 16, None, 17) == native.EINVAL
-    assert L.mi355ntt_poly_negate_raw(native.vp(8), 16, None, 17) == native.EINVAL                 # misaligned
+    assert L.mi355ntt_poly_negate_raw(native.vp(4), 16, None, 17) == native.EINVAL                 # not even a word boundary
+    # pointers that are word- but not 16-byte aligned (a + odd offset) are transformed, as by the reference's kernels:
+    # the one-word-per-lane form of every wrapper against the same restatements
+    q = P.Q60[0]
+    a = rng.integers(0, q, size=2050, dtype=np.uint64)
+    b = rng.integers(0, q, size=2050, dtype=np.uint64)
+    s = torch.cuda.current_stream()
+    for off_a, off_b in ((1, 0), (0, 1), (1, 1)):
+        da, db = native.to_device(a), native.to_device(b)
+        native.poly_add_device(da[off_a:], db[off_b:], 2048, s, q)
+        got = native.to_host(da)
+        assert np.array_equal(got[off_a: off_a + 2048], oracle.poly_add(a[off_a: off_a + 2048], b[off_b: off_b + 2048], q)), (off_a, off_b)
+        assert np.array_equal(got[:off_a], a[:off_a]) and np.array_equal(got[off_a + 2048:], a[off_a + 2048:])      # nothing outside
+        da = native.to_device(a)
+        native.poly_sub_device(da[off_a:], db[off_b:], 2048, s, q)
+        assert np.array_equal(native.to_host(da)[off_a: off_a + 2048], oracle.poly_sub(a[off_a: off_a + 2048], b[off_b: off_b + 2048], q))
+    da = native.to_device(a)
+    native.poly_negate_device(da[1:], 2048, s, q)
+    assert np.array_equal(native.to_host(da)[1:2049], oracle.poly_negate(a[1:2049], q))
+    da = native.to_device(a)
+    native.poly_add_integer_device(da[1:], 77, 2048, s, q)
+    assert np.array_equal(native.to_host(da)[1:2049], oracle.poly_add_integer(a[1:2049], 77, q))
+    da = native.to_device(a)
+    native.poly_mul_int_t(da[1:], 3, 2048, s, 1024)
+    assert np.array_equal(native.to_host(da)[1:2049], oracle.poly_mul_int_t(a[1:2049], 3, 1024))
 
 
 def test_configs3_global_batch_8192_as_8_shards_on_one_gpu(native, oracle, gpu):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r04.json (read by bench.py).
+"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r05.json (read by bench.py).
 
 Compiles ntt-cuda_amd/csrc/kernels_fast_n15.hip to gfx950 assembly, sums the measured steady-state issue cost
 (tools/ubench_issue.hip, profiles/r02_ubench_issue_costs.txt) over the instructions of each kernel's polynomial loop
@@ -56,7 +56,7 @@ def loop_cost(lines, name_part):
 
 
 KERNELS = (("k_forward15", "k_forward15ILi4ELb1ELi0"), ("k_inverse15", "k_inverse15ILi4ELb1"), ("k_polymul15", "k_polymul15ILi4ELb1"))
-PROFILE = os.path.join(ROOT, "profiles", "valu_ceiling_r04.json")
+PROFILE = os.path.join(ROOT, "profiles", "valu_ceiling_r05.json")
 
 
 def ceiling_from_asm(lines):
@@ -108,7 +108,7 @@ def main():
         bad = drift(res, json.load(open(PROFILE)))
         for b in bad:
             print(b)
-        print("valu ceiling profile %s" % ("DRIFTED: regenerate profiles/valu_ceiling_r04.json" if bad else "in step with the shipped sources"))
+        print("valu ceiling profile %s" % ("DRIFTED: regenerate profiles/valu_ceiling_r05.json" if bad else "in step with the shipped sources"))
         return 1 if bad else 0
     json.dump(res, open(PROFILE, "w"), indent=1)
     print(json.dumps(res, indent=1))
