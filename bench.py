@@ -313,6 +313,39 @@ def bfv_round_trip(torch, ntt, n, dev, with_cpu, qs, psis, label):
     out = {"workload": "n=%d, %s, t=%d, 61-bit gamma; drivers after the samplers, one ciphertext" % (n, label, BFV_T),
            "keygen_us": keygen_us, "encrypt_us": encrypt_us, "decrypt_us": decrypt_us, "round_trip_ok": True}
 
+    # like for like with the reference's own timing (demo.cu:275-296 brackets keygen_rns / encryption_rns / decryption_rns, i.e.
+    # INCLUDING the Salsa20 keystream and the samplers; Article.pdf p26 Table 7): the complete drivers, one ciphertext per call,
+    # GPU time by events over back-to-back calls (fresh nonce each)
+    sk1 = torch.zeros(R, n, dtype=torch.int64, device=dev)
+    pk1 = torch.zeros(2, R, n, dtype=torch.int64, device=dev)
+    tmp = torch.zeros(R, n, dtype=torch.int64, device=dev)
+    rk = torch.zeros(ctx.keygen_random_bytes, dtype=torch.uint8, device=dev)
+    re_ = torch.zeros(ctx.encrypt_random_bytes, dtype=torch.uint8, device=dev)
+    c1 = torch.zeros(2, R, n, dtype=torch.int64, device=dev)
+    e1_ = torch.zeros(2, R, n, dtype=torch.int64, device=dev)
+
+    def b2b(fn, reps=50):
+        for i in range(5):
+            fn(i)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(reps):
+            fn(100 + i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    kg_full = b2b(lambda i: ctx.keygen_rns(rk, sk1, pk1, tmp, nonce=i))
+    en_full = b2b(lambda i: ctx.encryption_rns(c1, pk1, re_, e1_, m, nonce=i))
+    ctx.encryption_rns(c1, pk1, re_, e1_, m, nonce=7)
+    c_full = c1.clone()
+    de_full = b2b(lambda i: (c1.copy_(c_full), ctx.decrypt(c1, sk1)))       # (decryption overwrites its input: the copy is inside the bracket, ~2 us)
+    ok_full = bool(torch.equal(c1.reshape(-1)[off: off + n], m))
+    out["complete_drivers_including_keystream_and_samplers"] = {
+        "keygen_rns_us": kg_full, "encryption_rns_us": en_full, "decryption_rns_us": de_full, "round_trip_ok": ok_full,
+        "what": "mi355ntt_bfv_keygen_rns / _encryption_rns (Salsa20/20 keystream -> samplers -> transforms) and mi355ntt_bfv_decrypt, one ciphertext per call, "
+                "50 calls back to back between two events -- the bracket of demo.cu:275-296"}
+
     # the batched drivers: 64 ciphertexts per call, layout [2][64][R][n]; same public/secret key, fresh u / e / m each
     B = 64
     ub = torch.stack([ternary() for _ in range(B)])
@@ -762,7 +795,13 @@ def main():
 
         # ---- sustained run with package power / shader clock sampled (the kernels sit at the package power cap) ----
         power = None
+        smi_exe = os.path.join(ROOT, "ntt-cuda_amd", "build", "smi_watch")
+        smi_proc = None
         try:
+            if os.path.exists(smi_exe):       # the SMU's own accounting (rocm_smi gpu_metrics): throttler residencies -> PVIOL / TVIOL
+                pr = torch.cuda.get_device_properties(dev)
+                bdf = ["%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))] if isinstance(getattr(pr, "pci_bus_id", None), int) else []
+                smi_proc = subprocess.Popen([smi_exe, "100", "0"] + bdf, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             with PowerSampler() as ps:
                 # ~3 s of headline steps in chunks of 200, at most two chunks queued (the host waits for the event of the chunk before
                 # the previous one: the GPU never runs dry, the queue never grows)
@@ -778,17 +817,67 @@ def main():
                 torch.cuda.synchronize()
                 el_s = time.perf_counter() - t_s
                 nst = 200 * chunks
+            smu = None
+            if smi_proc is not None:
+                smi_proc.terminate()
+                rows = [json.loads(l) for l in smi_proc.communicate(timeout=10)[0].splitlines() if l.startswith("{") and "error" not in l]
+                smi_proc = None
+                rows = rows[8:] if len(rows) > 12 else rows          # (first 0.8 s dropped, as below)
+                if len(rows) >= 2:
+                    a_, b_ = rows[0], rows[-1]
+                    acc = max(1, b_["acc_counter"] - a_["acc_counter"])
+                    smu = {"samples": len(rows), "socket_power_w_mean": sum(r["power_w"] for r in rows) / len(rows),
+                           "gfxclk_mhz_mean": sum(r["gfxclk_mhz"] for r in rows) / len(rows), "hotspot_c_max": max(r["hotspot_c"] for r in rows),
+                           "pviol_pct": (b_["ppt_acc"] - a_["ppt_acc"]) * 100.0 / acc, "tviol_pct": (b_["thm_acc"] - a_["thm_acc"]) * 100.0 / acc,
+                           "hbm_thermal_pct": (b_["hbm_thm_acc"] - a_["hbm_thm_acc"]) * 100.0 / acc, "vr_thermal_pct": (b_["vr_thm_acc"] - a_["vr_thm_acc"]) * 100.0 / acc,
+                           "prochot_pct": (b_["prochot_acc"] - a_["prochot_acc"]) * 100.0 / acc,
+                           "how": "rocm_smi gpu_metrics every 0.1 s (tools/smi_watch.cpp): PVIOL % = share of the SMU's accumulation cycles in which the "
+                                  "package-power-tracking (PPT) limiter held the clock down, TVIOL % the same for the socket thermal limiter"}
             mid = [x for x in ps.samples if 0.8 < x[0] < el_s]
             if mid:
                 power = {"pairs_per_s": batch * nst / el_s, "seconds": el_s, "samples": len(mid),
                          "package_power_w_mean": sum(x[2] for x in mid) / len(mid), "package_power_w_max": max(x[2] for x in mid),
                          "sclk_mhz_mean": (sum(x[1] for x in mid if x[1]) / max(1, len([x for x in mid if x[1]]))),
-                         "power_cap_w": ps.cap,
+                         "power_cap_w": ps.cap, "smu": smu,
                          "how": "rocm-smi --showpower --showclocks every 0.25 s during %.1f s of back-to-back headline steps (first 0.8 s dropped)" % el_s}
+                # the fitted package-power model (tools/power_model.hip -> tools/power_fit.py -> profiles/rNN_power_model_fit.json): what
+                # this operating point says about the kernels' own energy per pair, and the pairs/s the cap would admit at other VALU
+                # utilisations (the clock the SMU would have to choose falls as the utilisation rises)
+                fpath = newest_profile("r%02d_power_model_fit.json")
+                if fpath and power["sclk_mhz_mean"] and valu:
+                    try:
+                        fit = json.load(open(fpath))
+                        cyc = valu["k_forward15"]["cycles_per_polynomial_per_cu"] + valu["k_inverse15"]["cycles_per_polynomial_per_cu"]
+                        T, f_, w_ = power["pairs_per_s"], power["sclk_mhz_mean"] * 1e-3, power["package_power_w_mean"]
+                        S_, A_, al_, M_, be_, f0_ = fit["S_w"], fit["A_w"], fit["alpha"], fit["M_w"], fit["beta"], fit["f0_ghz"]
+                        tb = 2 * BYTES_PER_TRANSFORM * 1.03 / 1e12
+                        u_ = T * cyc / (cus * f_ * 1e9)
+                        e_l = (w_ - S_ - A_ * u_ * (f_ / f0_) ** al_ - M_ * (tb * T) ** be_) / T
+                        pred = {}
+                        for ut in (0.75, 0.85, 1.0):
+                            lo, hi = 1e6, 8e6
+                            for _ in range(50):
+                                Tm = 0.5 * (lo + hi)
+                                fm = min(Tm * cyc / (cus * ut * 1e9), 2.4)
+                                um = Tm * cyc / (cus * fm * 1e9)
+                                if S_ + A_ * um * (fm / f0_) ** al_ + M_ * (tb * Tm) ** be_ + e_l * Tm > w_:
+                                    hi = Tm
+                                else:
+                                    lo = Tm
+                            pred["%.2f" % ut] = lo
+                        power["model"] = {"fit": os.path.relpath(fpath, ROOT), "form": fit["model"] + " + E_L x pairs/s",
+                                          "valu_utilisation_of_this_run": u_, "E_L_joule_per_pair": e_l,
+                                          "pairs_per_s_the_same_power_admits_at_valu_utilisation": pred,
+                                          "note": "a 256 MiB batch is partly served by the memory-side cache: its HBM term is an upper bound, E_L absorbs the difference"}
+                    except Exception as exc:
+                        power["model"] = {"error": repr(exc)}
             else:
                 power = {"error": "no rocm-smi samples"}
         except Exception as exc:
             power = {"error": repr(exc)}
+        finally:
+            if smi_proc is not None:
+                smi_proc.kill()
         assert torch.equal(a, a0)
         # the VALU ceiling once more at the clock the chip HOLDS under this load (the clock probe above runs behind the launches, when
         # the load is gone and the clock has already jumped: it reads ~2.4 GHz where rocm-smi shows ~2.25 GHz during the run)
@@ -879,7 +968,10 @@ def main():
                              bfv_round_trip(torch, ntt, n, dev, False, DEMO_Q16, DEMO_PSI16, "the 16 primes of demo.cu:35-36 (log q = 880)"),
                              reference_published_v100_us={"keygen": 427.81, "encrypt": 514.73, "decrypt": 246.48, "includes": "samplers",
                                                           "source": "Article.pdf p26 Table 7"})}
-    if args.end_to_end:
+    if use_pg:
+        out["collective"] = {"backend": dist.get_backend(), "world_size_observed": dist.get_world_size(),
+                             "role": "barrier + MAX all-reduce of the timing bracket; scatter / gather of a root-resident batch (end_to_end); no collective on the data path of `value`"}
+    if args.end_to_end or world > 1:          # N > 1: both figures of SURVEY.md 8(e) in the one line -- `value` (device-resident shards) and end_to_end
         # SURVEY.md 8(e) report 2: the batch lives on rank 0; chunked scatter / transform / gather (ntt_cuda_amd/shard.py)
         try:
             from ntt_cuda_amd import shard

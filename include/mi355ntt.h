@@ -135,8 +135,13 @@ const mi355ntt_u64* mi355ntt_ctx_psiinv_tables(const mi355ntt_ctx* ctx);
  * call on another stream while such a launch is still in flight, any call on a capturing stream and any call on a stream created
  * with a CU mask runs the single-workgroup launch instead (same words, ~10 % slower); the hand-over costs one hipEventRecord /
  * hipEventQuery on the host.  A workgroup whose partner has not become resident after 30 s of wall clock (the GPU's constant
- * 100 MHz counter, independent of the shader clock) aborts the kernel (hipErrorLaunchFailure at the next synchronisation) rather
- * than hang: that can only happen when another workload holds the device's CUs indefinitely.
+ * 100 MHz counter, independent of the shader clock) GIVES UP rather than hang: it stores nothing, marks the launch dead (other
+ * workgroups left without a partner, in this launch or in cooperating launches queued behind it, then end within 100 us) and raises a
+ * host-visible error word; the next call
+ * that wants a cooperating launch on that device returns MI355NTT_EHIP (mi355ntt_last_hip_error() = hipErrorLaunchFailure) without
+ * launching and clears the condition, so the call after it runs normally.  The data of the launch that gave up is invalid, as after any
+ * asynchronous device fault -- but the process keeps its device context (no trap).  This can only happen when another workload holds
+ * the device's CUs indefinitely.
  * ---------------------------------------------------------------------------------------------- */
 /* forwardNTT (ntt_60bit.cuh:314-348): one polynomial, prime prime_idx */
 int mi355ntt_forward(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream stream);

@@ -120,12 +120,59 @@ hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, 
 struct PairSlot;
 constexpr unsigned kPairFlagWords = 2048;               // zeroed 32-bit words; flags[2 pair + role], grid <= 1024 workgroups
 hipError_t pair_init_current_device();                  // allocates the current device's slot (idempotent)
-PairSlot* pair_acquire(hipStream_t s);
+// status (may be null): hipErrorLaunchFailure when an EARLIER pair launch on this device gave up on a partner (see the watchdog below) --
+// the slot is then cleaned (flags zeroed in stream order) and null returned: the caller reports the error instead of launching
+PairSlot* pair_acquire(hipStream_t s, hipError_t* status = nullptr);
 void pair_release(PairSlot* slot, hipStream_t s);
 unsigned* pair_flags(PairSlot* slot);
-// watchdog of the spinning workgroups, in ticks of the 100 MHz constant clock (s_memrealtime): a partner that has not become resident
-// after this long means another tenant holds the CUs indefinitely; the kernel then aborts (hipErrorLaunchFailure) rather than hang
+// Watchdog of the spinning workgroups, in ticks of the 100 MHz constant clock (s_memrealtime): a partner that has not become resident
+// after this long means another tenant holds the CUs indefinitely.  The workgroup then GIVES UP instead of hanging (or trapping, which
+// would take the process's device context with it): it sets the last word of the flag buffer -- a workgroup of this or of a later
+// pair launch that finds it set while waiting for its own partner ends after 100 us instead of 30 s -- and the host-mapped error word; the library reports
+// MI355NTT_EHIP (hipErrorLaunchFailure) from the next call that wants the pair slot and cleans it.  The data of the launch that
+// gave up is invalid (as after any asynchronous device fault).  MI355NTT_PAIR_WATCHDOG_MS in the environment shortens it (tests).
 constexpr unsigned long long kPairWatchdogTicks = 30ull * 100000000ull;      // 30 s
+// tail of the flag buffer (grids use at most kPairFlagWords / 2 words): what a workgroup that gives up needs, written once by the host
+constexpr unsigned kPairDeadWord = kPairFlagWords - 1;        // != 0: a workgroup of this or an earlier launch gave up
+constexpr unsigned kPairErrPtrWord = kPairFlagWords - 4;      // u64: device pointer of the host-mapped error word
+constexpr unsigned kPairTicksWord = kPairFlagWords - 6;       // u64: the watchdog in 100 MHz ticks
+constexpr unsigned kPairLiveWords = kPairFlagWords - 8;       // words [0, kPairLiveWords) are the flags proper
+unsigned long long pair_watchdog_ticks();
+#ifdef __HIPCC__
+// device side: the poll loop's slow path, on the SCALAR unit (s_load ... glc: coherent, no VGPR): formed as vector loads the three
+// tail addresses are loop invariants, hoisted out of the polynomial loop into VGPR pairs that stay live through every round --
+// measured: k_forward15_pair went from 112-120 VGPRs without scratch to 128 VGPRs with 24-52 bytes of it.
+__device__ __forceinline__ unsigned pair_tail_u32(const unsigned* flags, unsigned word)
+{
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, %2 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(flags), "s"(word * 4u) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned long long pair_tail_u64(const unsigned* flags, unsigned word)
+{
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(flags), "s"(word * 4u) : "memory");
+    return v;
+}
+__device__ __forceinline__ bool pair_launch_is_dead(const unsigned* flags) { return pair_tail_u32(flags, kPairDeadWord) != 0; }
+// called from the poll loop: ENDS THE WAVE (s_endpgm: noreturn, like the trap it replaces) when the launch is dead or the watchdog has
+// expired
+// (the scalar loads go to L2 and wait: microseconds under load.  A poll loop therefore calls this only once it has been waiting for
+// kPairSlowPollTicks -- until then it costs what it cost with the trap, one s_memrealtime per iteration; polled every iteration the
+// pair forward lost a third: 0.280 against 0.192 ms per 512 polynomials)
+constexpr unsigned long long kPairSlowPollTicks = 10000ull;      // 100 us
+__device__ __forceinline__ void pair_watchdog_check(unsigned* flags, unsigned long long t0)
+{
+    if (__builtin_amdgcn_s_memrealtime() - t0 <= kPairSlowPollTicks) return;
+    if (pair_launch_is_dead(flags)) __builtin_amdgcn_endpgm();
+    if (__builtin_amdgcn_s_memrealtime() - t0 <= pair_tail_u64(flags, kPairTicksWord)) return;
+    unsigned* err = reinterpret_cast<unsigned*>(pair_tail_u64(flags, kPairErrPtrWord));
+    __hip_atomic_store(flags + kPairDeadWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(err, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_endpgm();
+}
+#endif
 
 // ---- the reference's 30-bit path (kernels_ntt30.hip): 32-bit words, single prime, `num` polynomials of n words ----
 // ninv_native: m^-1 mod q (m = n, or n / 2 at n = 2^16) when the call may run the native kernels, 0 = literal kernels only

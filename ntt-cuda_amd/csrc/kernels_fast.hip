@@ -99,6 +99,8 @@ struct PairSlot {
     hipEvent_t done = nullptr;
     hipStream_t owner = nullptr;
     bool in_flight = false;
+    volatile unsigned* h_err = nullptr;      // host-mapped: written by a workgroup that gave up on its partner (kernels.hpp, watchdog)
+    unsigned* d_err = nullptr;               // the same word as the device sees it
 };
 namespace {
 constexpr int kMaxDevices = 64;
@@ -126,11 +128,25 @@ hipError_t pair_init_locked(PairSlot& p)
     unsigned* f = nullptr;
     hipError_t e;
     if ((e = hipMalloc((void**)&f, kPairFlagWords * sizeof(unsigned))) != hipSuccess) return e;
+    void* h = nullptr;
+    void* d = nullptr;
     if ((e = hipMemset(f, 0, kPairFlagWords * sizeof(unsigned))) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipHostMalloc(&h, 64, hipHostMallocMapped)) != hipSuccess || (e = hipHostGetDevicePointer(&d, h, 0)) != hipSuccess) {
+        if (h) (void)hipHostFree(h);
         (void)hipFree(f);
         return e;
     }
+    std::memset(h, 0, 64);
+    const unsigned long long tail[2] = {pair_watchdog_ticks(), (unsigned long long)reinterpret_cast<uintptr_t>(d)};      // kPairTicksWord, kPairErrPtrWord
+    static_assert(kPairErrPtrWord == kPairTicksWord + 2, "tail layout");
+    if ((e = hipMemcpy(f + kPairTicksWord, tail, sizeof(tail), hipMemcpyHostToDevice)) != hipSuccess) {
+        (void)hipHostFree(h);
+        (void)hipFree(f);
+        return e;
+    }
+    p.h_err = static_cast<volatile unsigned*>(h);
+    p.d_err = static_cast<unsigned*>(d);
     p.d_flags = f;
     return hipSuccess;
 }
@@ -147,8 +163,19 @@ hipError_t pair_init_current_device()
 }
 
 // the slot when stream s may launch a pair kernel now, else null; pair_release records the launch
-PairSlot* pair_acquire(hipStream_t s)
+unsigned long long pair_watchdog_ticks()
 {
+    static const unsigned long long ticks = [] {
+        const char* e = std::getenv("MI355NTT_PAIR_WATCHDOG_MS");
+        const long ms = e ? std::atol(e) : 0;
+        return ms > 0 ? (unsigned long long)ms * 100000ull : kPairWatchdogTicks;
+    }();
+    return ticks;
+}
+
+PairSlot* pair_acquire(hipStream_t s, hipError_t* status)
+{
+    if (status) *status = hipSuccess;
     static const bool off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;      // (A/B measurements)
     if (off) return nullptr;
     int dev = 0;
@@ -167,6 +194,20 @@ PairSlot* pair_acquire(hipStream_t s)
     if (!ok) {
         (void)hipGetLastError();                                    // (hipErrorNotReady of the query is not an error of this call)
         g_pair_mutex.unlock();
+        return nullptr;
+    }
+    if (p.h_err && *p.h_err != 0) {
+        // an earlier pair launch gave up on a partner: its data is invalid and the flags are in an arbitrary state.  Clean the slot
+        // behind whatever is still queued on this stream (every queued pair launch finds the dead word and returns at once) and
+        // report; the next call starts from a clean slot.
+        *p.h_err = 0;
+        (void)hipMemsetAsync(p.d_flags, 0, kPairLiveWords * sizeof(unsigned), s);
+        (void)hipMemsetAsync(p.d_flags + kPairDeadWord, 0, sizeof(unsigned), s);
+        p.owner = s;
+        p.in_flight = (hipEventRecord(p.done, s) == hipSuccess);
+        if (!p.in_flight) (void)hipStreamSynchronize(s);
+        g_pair_mutex.unlock();
+        if (status) *status = hipErrorLaunchFailure;
         return nullptr;
     }
     p.owner = s;
@@ -352,12 +393,14 @@ bool fast_inverse_split16_ok(const FastTables& t, unsigned num, bool product) { 
 hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
     // two workgroups per polynomial (k_forward15_pair: 1 x / 1 x traffic) when this stream may own the device's pair flags
-    if (PairSlot* slot = fast_fwd_pair_ok_16(t.hl) ? pair_acquire(s) : nullptr) {
+    hipError_t st = hipSuccess;
+    if (PairSlot* slot = fast_fwd_pair_ok_16(t.hl) ? pair_acquire(s, &st) : nullptr) {
         const hipError_t e = fast_fwd_pair_16(t.hl, d_a, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const PrimeDev*>(t.d_primes),
                                               num, division, prime_base, s, slot->d_flags);
         pair_release(slot, s);
         return e;
     }
+    if (st != hipSuccess) return st;                     // (an earlier pair launch gave up on a partner: reported here, nothing launched)
     return fast_fwd_split_16(t.hl, d_a, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const PrimeDev*>(t.d_primes), num,
                              division, prime_base, s);
 }

@@ -493,20 +493,24 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
         return flags + f;
     };
     unsigned it = 0;
-    // the partner has read the input under this result?  (long since, normally.  A partner that never shows up -- 30 s of wall clock, kPairWatchdogTicks --
-    // means the grid is not resident as a whole, which the launch rules exclude: abort the kernel, loudly, rather than hang or
-    // store over words the partner still needs)
+    // the partner has read the input under this result?  (long since, normally.  A partner that never shows up -- 30 s of wall clock,
+    // kernels.hpp -- means the grid is not resident as a whole, which the launch rules exclude.  The workgroup then gives up: it
+    // marks the launch dead -- every workgroup that finds the mark while it waits for a partner, in this launch or in pair launches
+    // queued behind it, ends within 100 us instead of waiting out its own watchdog -- writes the host-visible error word and ends; no hang, no store over words the partner still needs,
+    // and no trap: the process keeps its device context and learns of the failure at its next pair call, kernels.hpp.)
     auto wait_for_partner = [&]() {
         unsigned* const partner_flag = flag_at(1u - role);
         if (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > it) return;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // (watchdog by the constant 100 MHz clock, not by iterations)
         while (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
             __builtin_amdgcn_s_sleep(8);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > kPairWatchdogTicks) __builtin_trap();
+            pair_watchdog_check(flags, t0);               // (ends the wave when the launch is dead or the watchdog has expired)
         }
     };
     unsigned y = pair;
     if (y >= num) return;
+    // (no check of the dead mark here: an s_load ... glc + return in front of the first loads cost the kernel a third of its time --
+    // 0.281 against 0.184 ms per 512 polynomials, measured -- and a workgroup of a dead launch notices in its poll loop anyway)
     {
         const unsigned ph = (w >> 4) & 7u, units = ph * (num > npairs ? (unsigned)MI355NTT_STAGGER_FWD_MULTI : (unsigned)MI355NTT_STAGGER_FWD);
         for (unsigned i = 0; i < units; i++) __builtin_amdgcn_s_sleep(32);
@@ -565,7 +569,7 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
         ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
-        wait_for_partner();
+        wait_for_partner();                               // (a wave that gives up ends here: nothing is stored; ended waves leave the workgroup's barriers)
         asm volatile("" ::: "memory");                    // (compiler-level order: nothing of the row store moves above the poll)
         wave_store_rows(v, slice, make_rsrc(a + (size_t)(2 * y + role) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
         it++;
@@ -969,8 +973,11 @@ inline void dispatch_class(int hl, F&& f)
     } else {
         if (h >= 6) f(integral_constant<int, 6>{}, integral_constant<bool, false>{});
         else if (h >= 4) f(integral_constant<int, 4>{}, integral_constant<bool, false>{});
-        // (general 61-bit primes stay in class 2: their per-stage partial reduction is the 7-instruction form, and with it the class-3
-        // inverse and fused kernels need 36-52 bytes of scratch per lane at n = 2^13 .. 2^15 -- measured with the compiler's remarks)
+        // (general 61-bit primes, round 5: class 3 -- three-product quotient estimates instead of exact 64 x 64 high products.  Their
+        // inverse rounds restore the bound by ONE conditional subtraction of 4q per reducing sum, gs_round; with the 7-instruction
+        // general reduction there the class-3 inverse and fused kernels needed 28-52 bytes of scratch per lane, which kept these
+        // primes in class 2 until round 4)
+        else if (WITH3 && h == 3) f(integral_constant<int, WITH3 ? 3 : 2>{}, integral_constant<bool, false>{});
         else f(integral_constant<int, 2>{}, integral_constant<bool, false>{});
     }
 }
@@ -1128,7 +1135,7 @@ MI355NTT_DECLARE_SIZE(14)
 MI355NTT_DECLARE_SIZE(15)
 bool fast_split_ok_16(unsigned num, int op, bool pair);   // (kernels_fast_n16.hip; op: 0 forward, 1 inverse, 2 fused product)
 hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
-                            hipStream_t s, unsigned* d_flags);      // (two workgroups per polynomial; d_flags: kPairFlagWords zeroed words)
+                            hipStream_t s, unsigned* d_flags);      // (two workgroups per polynomial; d_flags: the device's pair-flag buffer, kernels.hpp)
 bool fast_fwd_pair_ok_16(int hl);                         // (headroom classes 4 and 6)
 hipError_t fast_inv_split_16(int hl, u64* d_a, const u64* d_bhat, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,
                              unsigned base, hipStream_t s);       // (d_bhat: null, or the pointwise factor applied on the way in)

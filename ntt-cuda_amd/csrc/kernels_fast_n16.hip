@@ -20,16 +20,26 @@ static bool split_ok(unsigned num, int op, bool pair)
     const unsigned from = op == 0 ? (pair ? 72u : 120u) : op == 1 ? 120u : 96u;
     return num >= from;
 }
+// Classes 5 (59-bit near-2^k) and 3 (61-bit near-2^k: the shape of the reference's gamma, demo.cu:93) have kernels of their own here
+// since round 5 (before: folded into classes 4 and 2).  MI355NTT_N16_NO_CLASS35=1 folds them again (A/B measurements).
+static bool fold_classes_35()
+{
+    static const bool on = std::getenv("MI355NTT_N16_NO_CLASS35") != nullptr;
+    return on;
+}
 static hipError_t launch_fwd_split16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                                      hipStream_t s)
 {
 #ifndef MI355NTT_ONLY_HL4N
     dim3 g(persistent_grid<15>(num)), b(1024);
-    dispatch_class<false>(hl, [&](auto hc, auto nc) {
+    auto go = [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
         k_forward15<H, NR, 1><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-    });
+    };
+    // (forward: classes 5 / 3 stay folded into 4 / 2 -- their own instantiations of this kernel need 16 / 24 bytes of scratch and measure
+    // no faster, 0.232 against 0.228 ms per 512 polynomials at 61 bits; the inverse and fused forms below gain 10 % / 7 % from class 3)
+    dispatch_class<false>(hl, go);
 #endif
     return hipGetLastError();
 }
@@ -39,12 +49,14 @@ static hipError_t launch_inv_split16(int hl, u64* d_a, const u64* d_bhat, const 
 {
 #ifndef MI355NTT_ONLY_HL4N
     dim3 g(persistent_grid<15>(num)), b(1024);
-    dispatch_class<false>(hl, [&](auto hc, auto nc) {
+    auto go = [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
         if (d_bhat) k_inverse15_split<H, NR, true><<<g, b, 0, s>>>(d_a, d_bhat, tw, pr, division, base, num);
         else k_inverse15_split<H, NR, false><<<g, b, 0, s>>>(d_a, nullptr, tw, pr, division, base, num);
-    });
+    };
+    if (fold_classes_35()) dispatch_class<false>(hl, go);
+    else dispatch_class<true>(hl, go);
 #endif
     return hipGetLastError();
 }

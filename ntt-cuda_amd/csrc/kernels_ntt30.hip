@@ -638,14 +638,14 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
             if constexpr (PAIR) {
                 // V of the next polynomial in front of the stores (results return in order: behind them it would wait for their
                 // drain), then: has the partner read the input under this result?  (long since, normally; a partner that never
-                // shows up -- 30 s of wall clock, kPairWatchdogTicks -- means the grid is not resident as a whole: abort loudly rather than hang)
+                // shows up -- 30 s of wall clock -- means the grid is not resident as a whole: the workgroup gives up, kernels.hpp, rather than hang)
                 issue_loads_v(more ? y + stride : y, more);
                 unsigned* const pf = flag_at(1u - h);
                 if (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // (watchdog by the constant 100 MHz clock)
                     while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
                         __builtin_amdgcn_s_sleep(8);
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > kPairWatchdogTicks) __builtin_trap();
+                        pair_watchdog_check(flags, t0);      // (gives up -- ends the wave -- without storing: kernels.hpp)
                     }
                 }
                 asm volatile("" ::: "memory");            // (compiler-level order: no store of the result moves above the poll)
@@ -688,7 +688,7 @@ k_ntt30x(u32* __restrict__ a, const Scratch30* __restrict__ sc, u32 q, unsigned 
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= it) {
                             __builtin_amdgcn_s_sleep(8);
-                            if (__builtin_amdgcn_s_memrealtime() - t0 > kPairWatchdogTicks) __builtin_trap();      // (the partner never became resident: see the forward form)
+                            pair_watchdog_check(flags, t0);      // (the partner never became resident: see the forward form)
                         }
                     }
                     // compiler-level acquire: the (non-volatile) buffer loads of Y below must not be hoisted above the poll -- the
@@ -852,7 +852,9 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     unsigned pgrid = 0;
     PairSlot* slot = nullptr;
     if (split && num >= (FWD ? kPair30MinPolysFwd : kPair30MinPolysInv) && (pgrid = pair_grid(cnt)) != 0) {
-        if ((slot = pair_acquire(s)) == nullptr) pgrid = 0;
+        hipError_t pst = hipSuccess;
+        if ((slot = pair_acquire(s, &pst)) == nullptr) pgrid = 0;
+        if (pst != hipSuccess) return pst;                // (an earlier pair launch gave up on a partner: reported here, nothing launched)
     }
     const unsigned ninv_k = (pgrid && !FWD) ? (unsigned)(((u64)ninv_native * ((q + 1) / 2)) % q) : ninv_native;
     if (pgrid) {

@@ -993,6 +993,10 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
                     // exact-quotient class: S < 4q always, one conditional subtraction of 2q (5 instructions, no multiply, fewer
                     // temporaries than the general partial reduction -- with it these kernels spilled)
                     if constexpr (EX && !NEAR) S = csub(S, 2 * p.q);
+                    // general 61-bit primes (class 3, 8q < 2^64; round 5): a reducing stage sums two values below 4q, one conditional
+                    // subtraction of 4q restores the bound the policy assumes behind a reduction (max(TQ, 2) q = 4q) -- no multiply, no
+                    // reciprocal constants: with the 7-instruction general reduction the class-3 inverse and fused kernels spilled
+                    else if constexpr (HL == 3 && !NEAR) S = csub(S, 4 * p.q);
                     else S = reduce_2q_sel<NEAR>(S, p);
                 }
                 v[r0] = S;

@@ -26,6 +26,11 @@ Q60_SPECIAL, PSI60_SPECIAL = 1152921504595640321, 9679305630873
 GENERAL_PRIMES = {57: (93674872251744257, 1408945640707), 59: (536108499642941441, 7338562720162),
                   60: (818574268271493121, 19054799908346), 62: (3827699395296821249, 61619156825551)}
 
+# general 61-bit primes (= 1 mod 2^17, far from 2^61 or with 2^61 - q >= 2^24): class 3 with the conditional-subtract inverse since
+# round 5 (before: class 2, exact quotients): q -> {n: a primitive 2n-th root}
+GENERAL61 = {1609682519816667137: {32768: 1058825331674317735, 65536: 168149748110227714},
+             2305843009195868161: {32768: 323510840180264020, 65536: 1454513390878286822}}
+
 # the reference's first four 55-bit demo primes, BFV_Scheme/demo.cu:35-36 (entries 1..4 of the 16-prime set)
 Q55 = [36028797017456641, 36028797014704129, 36028797014573057, 36028797014376449]
 PSI55 = [1155186985540, 631260524634, 1526647220035, 455957817523]

@@ -332,6 +332,8 @@ KERNEL_FORMS = {
     # round 4: classes of their own for 61-bit and 59-bit near-2^k moduli (dispatch_class, kernels_fast_impl.cuh)
     "hl3-near": ([P.EDGE_PRIMES[61][0]], [P.EDGE_PRIMES[61][1][32768]]),
     "hl5-near": ([P.EDGE_PRIMES[59][0], P.EDGE_PRIMES[59][0]], [P.EDGE_PRIMES[59][1][32768], P.EDGE_PRIMES[59][1][32768]]),
+    # round 5: general 61-bit primes leave class 2 (three-product quotients, one conditional subtraction of 4q per reducing sum)
+    "hl3-general": (sorted(P.GENERAL61), [P.GENERAL61[q][32768] for q in sorted(P.GENERAL61)]),
 }
 
 

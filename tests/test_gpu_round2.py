@@ -115,12 +115,40 @@ def test_raw_api_falls_back_to_literal_kernels(native, oracle, gpu):
     native.inverseNTT_batch(d_a, n, d_ti, num, 4, mod)
     assert np.array_equal(host(native, d_a), a)
     assert not native.raw_trust_tables(n, d_tp, mod2)      # nothing to trust: a hand-made mu stays on the literal kernels
-    # (3) the untouched table still routes to the throughput kernels, and a modulus the reference's Barrett is inexact
-    # for (the second prime of decryption_test.cu) never does
+    # (3) the untouched table still routes to the throughput kernels.  A set that MIXES moduli on which the reference's Barrett is
+    # exact with one on which it is not -- the reference's own decryption_test.cu:47-48 set, prime 1 -- is routed per prime since
+    # round 5 (the derived context is a mixed one: two of three primes on the throughput kernels); a call whose moduli are ALL
+    # inexact stays on the literal kernels
     assert native.raw_uses_fast_kernels(n, d_tp, mod)
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat1_decryption_n4096.npz"))
-    kp = oracle.Params(int(z["n"]), z["q"], z["psi"])
-    assert not native.raw_uses_fast_kernels(int(z["n"]), dev(native, kp.psi_tabs), native.Moduli(z["q"]))
+    kn, kq = int(z["n"]), [int(x) for x in z["q"]]
+    kp = oracle.Params(kn, kq, z["psi"])
+    d_kt, d_kti, kmod = dev(native, kp.psi_tabs), dev(native, kp.psiinv_tabs), native.Moduli(z["q"])
+    assert native.raw_uses_fast_kernels(kn, d_kt, kmod)
+    one = oracle.Params(kn, kq[1:2], [int(z["psi"][1])])
+    assert not native.raw_uses_fast_kernels(kn, dev(native, one.psi_tabs), native.Moduli(kq[1:2]))
+    # ... with the reference's words for every prime: checked calls, a table rewritten in place under them (the literal share of the
+    # mixed context must stand back as well: inverted guard pair), ragged batches over several chunks of the gather buffer, trusted calls
+    for knum in (3, 7, 902):
+        ka = oracle.synth_batch(kn, knum, kq, 4100 + knum)
+        d_ka = dev(native, ka)
+        native.forwardNTT_batch(d_ka, kn, d_kt, knum, 3, kmod)
+        want = oracle.forward_batch(ka, kp, threads=THREADS)
+        assert np.array_equal(host(native, d_ka), want), knum
+        native.inverseNTT_batch(d_ka, kn, d_kti, knum, 3, kmod)
+        assert np.array_equal(host(native, d_ka), oracle.inverse_batch(want, kp, threads=THREADS)), knum
+    other = oracle.Params(kn, kq, [pow(int(p_), 3, q_) for p_, q_ in zip(z["psi"], kq)])      # psi^3: other primitive roots, other tables
+    keep = kp.psi_tabs.copy()
+    d_kt.copy_(dev(native, other.psi_tabs))                # same address, other contents: every prime must follow the NEW table
+    ka = oracle.synth_batch(kn, 10, kq, 77)
+    d_ka = dev(native, ka)
+    native.forwardNTT_batch(d_ka, kn, d_kt, 10, 3, kmod)
+    assert np.array_equal(host(native, d_ka), oracle.forward_batch(ka, other, threads=THREADS))
+    d_kt.copy_(dev(native, keep))
+    assert native.raw_trust_tables(kn, d_kt, kmod)
+    d_ka = dev(native, ka)
+    native.forwardNTT_batch(d_ka, kn, d_kt, 10, 3, kmod)
+    assert np.array_equal(host(native, d_ka), oracle.forward_batch(ka, kp, threads=THREADS))
 
 
 @pytest.mark.parametrize("n", [32768, 65536])

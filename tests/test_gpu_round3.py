@@ -146,6 +146,10 @@ N16_FORMS = {
     "hl4-general": [818574268271558657, P.Q60[0]],
     "hl2-near": [P.EDGE_PRIMES[62][0], P.EDGE_PRIMES[61][0]],
     "hl2-general": [3827699395297935361, P.Q60[1]],
+    # round 5: the split kernels are instantiated for classes 5 and 3 as well (the pair kernel folds them into 4 / the single-workgroup form)
+    "hl5-near": [P.EDGE_PRIMES[59][0]],
+    "hl3-near": [P.EDGE_PRIMES[61][0]],
+    "hl3-general": sorted(P.GENERAL61),
 }
 
 

@@ -264,3 +264,68 @@ def test_soak_checked_raw_calls_follow_the_table_contents(native, oracle, gpu):
         assert torch.equal(f, want[k][:cnt]), ("forward", it, k, cnt)
         assert torch.equal(w, a[:cnt]), ("round trip", it, k, cnt)
     native.raw_cache_clear()
+
+
+_WATCHDOG_CHILD = r"""
+import os, sys, time
+sys.path.insert(0, os.path.join(ROOT, "ntt-cuda_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import ntt_cuda_amd as ntt, params as P
+dev = torch.device("cuda", 0)
+n, num = 65536, 96
+qs = P.Q60[:2]
+psis = [next(x for x in (pow(g, (q - 1) // (2 * n), q) for g in range(2, 2000)) if pow(x, n, q) == q - 1) for q in qs]
+ctx = ntt.NTTContext(n, qs, psis)
+a = torch.empty((num, n), dtype=torch.int64, device=dev); ctx.synth_splitmix(a, num, 5)
+good = a.clone(); ctx.forward_batch(good, num); torch.cuda.synchronize()          # (a normal pair launch first: the reference words)
+cus = torch.cuda.get_device_properties(dev).multi_processor_count
+load, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+# (nearly) every CU held for 300 ms: a workgroup of the pair launch that becomes resident while its partner cannot gives up after 20 ms.
+# How many CUs must stay free for ONE workgroup to start is the dispatcher's business (workgroups are dealt to the XCDs round-robin;
+# on the development boxes one free CU starts nothing, two free CUs -- in two XCDs -- start two partner-less workgroups): try a few.
+wrong, gave_up_after, held = False, 0.0, 0
+for free in (2, 4, 1, 3, 6):
+    w = a.clone(); torch.cuda.synchronize()
+    ctx.occupy(cus - free, 300000, stream=load)
+    time.sleep(0.02)
+    t0 = time.perf_counter()
+    ctx.forward_batch(w, num, stream=s1)
+    torch.cuda.synchronize()
+    gave_up_after = time.perf_counter() - t0
+    wrong = not torch.equal(w, good)
+    if wrong:
+        held = cus - free
+        break
+# the next call that wants the pair slot reports it -- MI355NTT_EHIP, hipErrorLaunchFailure -- launches nothing and clears the condition
+w2 = a.clone(); torch.cuda.synchronize()
+code = hip = None
+try:
+    ctx.forward_batch(w2, num, stream=s1)
+except ntt.NTTError as e:
+    code, hip = e.code, ntt.lib().mi355ntt_last_hip_error()
+torch.cuda.synchronize()
+untouched = torch.equal(w2, a)
+# ... and the one after it runs normally: the process still has its device context
+w3 = a.clone(); torch.cuda.synchronize()
+ctx.forward_batch(w3, num, stream=s1)
+torch.cuda.synchronize()
+print("WATCHDOG wrong=%d held=%d seconds=%.2f code=%s hip=%s untouched=%d recovered=%d" % (wrong, held, gave_up_after, code, hip, untouched, torch.equal(w3, good)))
+ctx.close()
+"""
+
+
+def test_pair_watchdog_gives_up_without_killing_the_context(native, gpu):
+    """The cooperating-workgroup launch with all but a few CUs held by a foreign kernel for 300 ms and the watchdog shortened to 20 ms
+    (MI355NTT_PAIR_WATCHDOG_MS): the workgroup that becomes resident never sees its partner, gives up (no trap, no hang: the launch ends
+    within the foreign kernel's time, not after 256 x 20 ms -- the other workgroups find the launch marked dead and return), the next
+    call reports MI355NTT_EHIP / hipErrorLaunchFailure without touching its data, and the call after that gives the right words again in
+    the same process (the round-4 kernels ended in __builtin_trap, which takes the device context along)."""
+    env = dict(os.environ, MI355NTT_PAIR_WATCHDOG_MS="20")
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + _WATCHDOG_CHILD], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("WATCHDOG ")][-1]
+    f = dict(x.split("=") for x in line.split()[1:])
+    assert f["wrong"] == "1", line                       # (the launch that gave up stored nothing / not everything: flagged, not silently right)
+    assert float(f["seconds"]) < 2.0, line
+    assert int(f["code"]) == native.EHIP and int(f["hip"]) == 719, line          # hipErrorLaunchFailure
+    assert f["untouched"] == "1" and f["recovered"] == "1", line
