@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "ntt-cuda_amd"))
 sys.path.insert(0, ROOT)
 import torch
 import ntt_cuda_amd as ntt
+if os.environ.get('MI355NTT_LIB'):          # (A/B against another build of the library)
+    ntt.LIB_PATH = os.environ['MI355NTT_LIB']
 from ntt_cuda_amd import bfv
 from bench import Q60, PSI60, Q60_SPECIAL, PSI60_SPECIAL, DEMO_Q16, DEMO_PSI16, BFV_T, BFV_GAMMA, synth
 

@@ -8,7 +8,7 @@ otherwise the largest primes = 1 mod 2^16 below a bound far from a power of two,
 minimal primitive 2^16-th root, as the reference's are).  Every set is checked on the spot: inverse(forward(a)) == a and
 forward() of two sample polynomials against a Python evaluation of the transform at a few points.
 
-usage: python tools/sweep_classes.py [num=1024]     (GPU)        -> profiles/r04_kernel_classes.txt
+usage: python tools/sweep_classes.py [num=1024]     (GPU)        -> profiles/r05_kernel_classes.txt
 """
 import os
 import sys
@@ -88,7 +88,7 @@ def classes():
     c["hl4-general  (60-bit)"] = (primes_below(0xB3 << 52, 4), None)
     c["hl5-near     (59-bit)"] = (primes_below(1 << 59, 4), None)
     c["hl3-near     (61-bit)"] = (primes_below(1 << 61, 4), None)
-    c["hl2-general  (61-bit)"] = (primes_below(0xB3 << 53, 4), None)
+    c["hl3-general  (61-bit)"] = (primes_below(0xB3 << 53, 4), None)      # (class 2 until round 4)
     c["hl2-near     (62-bit)"] = (primes_below(1 << 62, 4), None)
     c["hl2-general  (62-bit)"] = (primes_below(0xB3 << 54, 4), None)
     return c
@@ -152,7 +152,8 @@ def main():
         tp = timeit(pair)
         tm = timeit(lambda: ctx.polymul_batch(a, b, num), reps=20, warm=40)
         hl = min(min(6, 64 - q.bit_length()) for q in qs)
-        kern = "<%d,%s>" % (6 if hl >= 6 else 5 if (hl == 5 and "near" in name) else 4 if hl >= 4 else 3 if (hl == 3 and "near" in name) else 2, "near" if "near" in name else "gen")
+        kc = ctx.kernel_class                          # (what the library chose: mi355ntt_ctx_kernel_class)
+        kern = "<%d,%s>" % (6 if kc[0] >= 6 else 5 if (kc[0] == 5 and kc[1]) else 4 if kc[0] >= 4 else 3 if kc[0] == 3 else 2, "near" if kc[1] else "gen")
         rows.append((name, tp))
         print("  %-52s %-6s %9.4f %9.4f %12.0f %14.0f %9.2f" % (name, kern, tf * 1e3, ti * 1e3, num / tp, num / tm, num * N * 16 / ti / 1e12))
         ctx.close()
