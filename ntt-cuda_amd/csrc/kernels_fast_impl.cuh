@@ -199,6 +199,18 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
 #define MI355NTT_PRIO_I3 2
 #endif
 #define MI355NTT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+// lab (round 5): priority by the wave's age on its SIMD (waves 4k .. 4k + 3 of a workgroup are the k-th oldest of their SIMDs) in the
+// round that feeds the workgroup-wide exchange: the SIMD arbitrates oldest first, so its four waves reach the barrier one after the
+// other; the youngest gets the highest priority there.  BASE + age, clamped to 3.
+__device__ __forceinline__ void setprio_by_age(unsigned wave_s, int base)
+{
+    const unsigned age = wave_s >> 2;
+    const int p = base + (int)age;
+    if (p <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
 // optional second priority inside a round: from scheduling group PSPLIT on (-1 = none) the wave runs at priority ..B
 #ifndef MI355NTT_PSPLIT_R1
 #define MI355NTT_PSPLIT_R1 -1
@@ -403,7 +415,11 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostic build only: separates the load wait from round 1
         MI355NTT_STAMPV(-1, 1);
 #endif
+#ifdef MI355NTT_PRIO_AGE_R1
+        setprio_by_age(wave_s, MI355NTT_PRIO_AGE_R1);
+#else
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
+#endif
         ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, 0u, p);   // (round 1 reads no thread-derived value)
         MI355NTT_STAMPV(1, 2);
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
@@ -628,7 +644,11 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         MI355NTT_STAMP2(it, 1);
         wave_transpose_0_to_5(v, slice, fresh_lane_id());
+#ifdef MI355NTT_PRIO_AGE_I2
+        setprio_by_age(wave_s, MI355NTT_PRIO_AGE_I2);
+#else
         MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
+#endif
         gs_round<LOGN, HL, 5, 0, NEAR, MI355NTT_PSPLIT_I2, MI355NTT_PRIO_I2B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         MI355NTT_STAMP2(it, 2);
         __syncthreads();                                  // private slices are idle from here on

@@ -331,6 +331,21 @@ def test_bench_two_ranks_on_one_gpu_dry_run(native, gpu):
     assert out["end_to_end"]["global_batch"] == 128
 
 
+def test_bench_line_survives_a_tail_that_does_not_finish(native, gpu):
+    """N > 1: what follows the timed region (end-to-end leg, process-group teardown) has never run across real devices on the build
+    boxes; bench.py therefore arms a timer in front of it -- when it expires rank 0 prints the contract line as it stands (`value` is
+    complete) and every rank leaves.  Forced here with a timeout of a millisecond on the two-rank dry run."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MI355NTT_BENCH_TAIL_TIMEOUT="0.001")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--batch", "64", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "end_to_end" in out
+
+
 def test_compiled_latency_harness_and_graph_capture(native, gpu):
     """tools/lat_bench.cpp (built by the package Makefile): the C ABI called from compiled code on a stream, replayed from captured
     hipGraphs (transforms and an encrypt -> decrypt graph) and call-by-call; the harness checks that the data survives every route
