@@ -100,10 +100,14 @@ static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsig
     // prime (for the exact ones they ARE the throughput kernels' words), no shared buffer)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-        if (base & kGuardBit) return hipSuccess;      // (checked raw call: raw_run's fallback leg, told to run unguarded, does the work)
-        const u64* t = (inverse ? c->d_psiinv : c->d_psi) + (size_t)base * c->n;
-        return inverse ? compat_inverse_batch(d_a, c->n, t, num, division, mods_from(c, base, division), s)
-                       : compat_forward_batch(d_a, c->n, t, num, division, mods_from(c, base, division), s);
+        // (inside a checked raw call -- raw_run sends captured mixed calls to the literal kernels itself, so this is belt and braces --
+        // the literal kernels run under the inverted guard pair: only when the caller's table is the context's; otherwise raw_run's
+        // own fallback leg transforms the data with the caller's table)
+        const unsigned pbc = base & ~kGuardBit;
+        const unsigned* g = (base & kGuardBit) ? static_cast<const unsigned*>(c->fast.d_primes_alloc) + 2 : nullptr;
+        const u64* t = (inverse ? c->d_psiinv : c->d_psi) + (size_t)pbc * c->n;
+        return inverse ? compat_inverse_batch(d_a, c->n, t, num, division, mods_from(c, pbc, division), s, g)
+                       : compat_forward_batch(d_a, c->n, t, num, division, mods_from(c, pbc, division), s, g);
     }
     // Checked raw calls (base carries kGuardBit; raw_run has compared the caller's table with the context's on the device): the
     // throughput kernels skip themselves when the tables differ, and so must the literal kernels on the gathered rows -- they run
