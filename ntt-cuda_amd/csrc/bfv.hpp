@@ -25,7 +25,7 @@ struct BfvPrime {
 struct BfvParams {
     unsigned n = 0, R = 0, r = 0;      // R = number of primes including the special last one, r = R - 1
     u64 t = 0, gamma = 0, mu_gamma = 0, gamma_div_2 = 0, m64_gamma = 0;    // m64_gamma: floor((2^64 - 1) / gamma), see BfvPrime::m64
-    unsigned gamma_bits = 0;
+    unsigned gamma_bits = 0, lazy_gamma = 1;               // lazy_gamma: Barrett products mod gamma (each below 2 gamma) that fit on a reduced accumulator in 64 bits
     u64 neg_inv_q_mod_t = 0, neg_inv_q_mod_gamma = 0;     // demo.cu:103-117
     u64 q_last = 0, half_q_last = 0;
     BfvPrime prime[kMaxPrimes];

@@ -33,6 +33,8 @@ int bfv_bootstrap(BfvParams* out, unsigned n, unsigned R, const u64* q, u64 t, u
     p.mu_gamma = barrett_mu(gamma, gbits);         // demo.cu:218-226
     p.gamma_div_2 = gamma >> 1;                    // demo.cu:94
     p.m64_gamma = ~0ULL / gamma;
+    p.lazy_gamma = (unsigned)((~0ULL - gamma) / (2 * (u128)gamma));      // (>= 1 for gamma < 2^62)
+    if (p.lazy_gamma < 1) p.lazy_gamma = 1;
     p.q_last = q[R - 1];
     p.half_q_last = p.q_last >> 1;
     const unsigned r = p.r;

@@ -172,12 +172,15 @@ k_decrypt_scale(u64* __restrict__ c, unsigned n, unsigned R, const BfvPrime* __r
     stv<V>(c1 + i, a1);
 }
 
-// poly_arithmetic.cuh:221-268, :128-142, barrett_int (:100-126) per column k.  The running sum's `% gamma` (:252) takes an
-// accumulator below gamma and a product below 2^64: reduce64; the final `% gamma` (:262) then finds a reduced value.
+// poly_arithmetic.cuh:221-268, :128-142, barrett_int (:100-126) per column k.  The reference reduces its running sum with `% gamma`
+// after every term (:252); every step is exact arithmetic mod gamma, so the sum may as well run LAZILY: a Barrett product is below
+// 2 gamma (the quotient estimate of Algorithm 7 is at most two short), so `lazy` = floor((2^64 - 1 - gamma) / (2 gamma)) terms fit on top
+// of a reduced accumulator without leaving 64 bits (3 for the reference's 61-bit gamma, never less than 1) -- one reduce64 per `lazy`
+// terms instead of one per term, the same residue in the end; the final `% gamma` (:262) then finds a reduced value.
 template <int V>
 __global__ void __launch_bounds__(kBlock)
 k_decrypt_round(u64* __restrict__ c, unsigned n, unsigned R, u64 t, u64 gamma, u64 mu_gamma, unsigned gamma_bits, u64 gamma_div_2,
-                u64 neg_inv_t, u64 neg_inv_gamma, const u64* __restrict__ bcm, size_t half_stride, u64 m64_gamma)
+                u64 neg_inv_t, u64 neg_inv_gamma, const u64* __restrict__ bcm, size_t half_stride, u64 m64_gamma, unsigned lazy)
 {
     const unsigned k = (blockIdx.x * kBlock + threadIdx.x) * V;
     const unsigned r = R - 1;
@@ -186,6 +189,7 @@ k_decrypt_round(u64* __restrict__ c, unsigned n, unsigned R, u64 t, u64 gamma, u
     const unsigned mask32 = (unsigned)(t - 1);                 // `unsigned mask = t - 1`
     const u64 mask = t - 1;                                    // dec_round_kernel
     u64 acc_t[V] = {}, acc_g[V] = {};
+    unsigned pending = 0;
     for (unsigned i = 0; i < r; i++) {
         u64 val[V];
         ldv<V>(val, c1 + k + (size_t)i * n);
@@ -193,8 +197,12 @@ k_decrypt_round(u64* __restrict__ c, unsigned n, unsigned R, u64 t, u64 gamma, u
 #pragma unroll
         for (int v = 0; v < V; v++) {
             acc_t[v] += (val[v] * bt) & mask32;                                          // fast_convert_array_kernel_t
-            const u64 tg = barrett_mul(val[v], bg, gamma, mu_gamma, gamma_bits);         // fast_convert_array_kernel_gamma
-            acc_g[v] = reduce64(acc_g[v] + tg, gamma, m64_gamma);
+            acc_g[v] += barrett_mul(val[v], bg, gamma, mu_gamma, gamma_bits);            // fast_convert_array_kernel_gamma (sum: lazily)
+        }
+        if (++pending == lazy || i + 1 == r) {
+#pragma unroll
+            for (int v = 0; v < V; v++) acc_g[v] = reduce64(acc_g[v], gamma, m64_gamma);
+            pending = 0;
         }
     }
     u64 x0[V], x1[V], res[V];
@@ -366,10 +374,10 @@ hipError_t bfv_decrypt_round(const BfvParams& p, const BfvDevice& d, u64* c, hip
     const size_t hs = (size_t)count * p.R * p.n;
     if (aligned16(c))
         k_decrypt_round<2><<<dim3(p.n / (2 * kBlock), 1, count), kBlock, 0, s>>>(c, p.n, p.R, p.t, p.gamma, p.mu_gamma, p.gamma_bits, p.gamma_div_2,
-                                                                              p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change, hs, p.m64_gamma);
+                                                                              p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change, hs, p.m64_gamma, p.lazy_gamma);
     else
         k_decrypt_round<1><<<dim3(p.n / kBlock, 1, count), kBlock, 0, s>>>(c, p.n, p.R, p.t, p.gamma, p.mu_gamma, p.gamma_bits, p.gamma_div_2,
-                                                                          p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change, hs, p.m64_gamma);
+                                                                          p.neg_inv_q_mod_t, p.neg_inv_q_mod_gamma, d.d_base_change, hs, p.m64_gamma, p.lazy_gamma);
     return hipGetLastError();
 }
 
