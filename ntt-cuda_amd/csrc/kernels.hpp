@@ -7,6 +7,10 @@
 namespace mi355ntt {
 
 constexpr unsigned kMaxPrimes = 16;
+// n = 2^15: tails of at most this many polynomials behind full rounds of the persistent grid run on the small-batch kernels
+// (kernels_fast.hip, tail_split_head; measured, tools/probe/tail_split_ab.py: fused product 195 against 229 us at 512 + 32 polynomials,
+// 207 / 229 at + 64, 221 / 234 at + 96, no gain from + 128 on; forward + inverse pairs 198 / 212, 214 / 223, 221 / 224)
+constexpr unsigned kTailSplitMax = 96, kTailSplitMaxFused = 100;
 
 // compute units of the CURRENT device (every launching entry point has switched to the context's device: device_scope.hpp);
 // sizes the persistent grids.  Cached per host thread and device; 256 (MI355X) only if the query itself fails.

@@ -370,8 +370,32 @@ hipError_t fast_probed_clock_mhz(const FastTables& t, double* mhz)
     return hipSuccess;
 }
 
+// n = 2^15, a batch of k full rounds of the persistent grid plus a short tail (round 5): a persistent launch pays a whole extra
+// iteration for the tail -- every workgroup that has no polynomial left idles while the others transform theirs -- so the tail runs on
+// the small-batch kernels instead (kernels_lat.cuh: a polynomial spread over 64 waves), in a launch sequence of its own behind the
+// head's.  Returns the number of polynomials of the head (a multiple of `division`: polynomial y' of the tail keeps prime
+// y' % division), 0 = no split.  Pays for tails of up to ~100 polynomials (kernels.hpp, kTailSplitMax*): beyond that the extra
+// persistent iteration costs no more than the small-batch launches.  MI355NTT_NO_TAIL_SPLIT=1 (A/B) and MI355NTT_LATENCY_PATH_MAX
+// (forced paths: tests) switch it off.
+static unsigned tail_split_head(const FastTables& t, unsigned num, unsigned division, bool fused)
+{
+    if (t.log_n != 15 || division == 0) return 0;
+    static const bool off = std::getenv("MI355NTT_NO_TAIL_SPLIT") != nullptr || std::getenv("MI355NTT_LATENCY_PATH_MAX") != nullptr;
+    if (off) return 0;
+    const unsigned cap = current_device_cus();
+    if (num <= cap || num % cap == 0) return 0;
+    unsigned head = (num / cap) * cap;
+    head -= head % division;
+    const unsigned tail = num - head;
+    return (head == 0 || tail > (fused ? kTailSplitMaxFused : kTailSplitMax)) ? 0 : head;
+}
+
 hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
+    if (const unsigned head = tail_split_head(t, num, division, false)) {
+        const hipError_t e = fast_forward_batch(t, d_a, head, division, prime_base, s);
+        return e != hipSuccess ? e : fast_forward_batch(t, d_a + (size_t)head * t.n, num - head, division, prime_base, s);
+    }
     const TwPair* tw = reinterpret_cast<const TwPair*>(t.d_fwd);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
     switch (t.log_n) {
@@ -414,6 +438,10 @@ hipError_t fast_inverse_split16(const FastTables& t, u64* d_a, unsigned num, uns
 
 hipError_t fast_inverse_batch(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
+    if (const unsigned head = tail_split_head(t, num, division, false)) {
+        const hipError_t e = fast_inverse_batch(t, d_a, head, division, prime_base, s);
+        return e != hipSuccess ? e : fast_inverse_batch(t, d_a + (size_t)head * t.n, num - head, division, prime_base, s);
+    }
     const TwPair* tw = reinterpret_cast<const TwPair*>(t.d_inv);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
     switch (t.log_n) {
@@ -442,10 +470,27 @@ hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, 
                               bool shared_b, unsigned group)
 {
     const unsigned plain_division = division;
-    if (shared_b) {
-        if (division > kDivisionMask || group >= (kSharedB >> kSharedGroupShift) || (group && group % division)) return hipErrorInvalidValue;
-        division |= kSharedB | (group << kSharedGroupShift);
+    if (shared_b && (division > kDivisionMask || group >= (kSharedB >> kSharedGroupShift) || (group && group % division))) return hipErrorInvalidValue;
+    if (unsigned head = tail_split_head(t, num, division, true)) {
+        // the tail's second operands: one per polynomial -> the same offset; shared by the batch -> the same `division` polynomials;
+        // shared per key group -> the group the tail lies in (one group: indexed from its start, no group arithmetic left), or, when
+        // the tail starts on a group boundary, the groups from there on
+        const u64* b_tail = d_bhat;
+        unsigned group_tail = group;
+        if (!shared_b) {
+            b_tail = d_bhat + (size_t)head * t.n;
+        } else if (group) {
+            const unsigned g0 = head / group, g1 = (num - 1) / group;
+            if (g0 == g1) { b_tail = d_bhat + (size_t)g0 * division * t.n; group_tail = 0; }
+            else if (head % group == 0) b_tail = d_bhat + (size_t)g0 * division * t.n;
+            else head = 0;                                   // (a tail across a group boundary that it does not start on: no split)
+        }
+        if (head) {
+            const hipError_t e = fast_polymul_batch(t, d_a, d_bhat, head, division, s, shared_b, group);
+            return e != hipSuccess ? e : fast_polymul_batch(t, d_a + (size_t)head * t.n, b_tail, num - head, division, s, shared_b, group_tail);
+        }
     }
+    if (shared_b) division |= kSharedB | (group << kSharedGroupShift);
     const TwPair* twf = reinterpret_cast<const TwPair*>(t.d_fwd);
     const TwPair* twi = reinterpret_cast<const TwPair*>(t.d_inv);
     const PrimeDev* pr = reinterpret_cast<const PrimeDev*>(t.d_primes);
