@@ -420,7 +420,21 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
 #else
         MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
 #endif
+#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 1
+        // lab: the next polynomial's lines of this wave (32 chunks of 512 B, 8 KiB apart) touched by two vector loads a whole iteration
+        // ahead of their use (round 1 reads its twiddles through the scalar cache: nothing waits behind them in the queue)
+        u32 tch0 = 0, tch1 = 0;
+        if (SPLIT == 0 && ynext < num) {
+            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N + wave_s * 64u, 32u * 8192u);
+            const u32 ln = fresh_lane_id(), tvoff = (ln >> 2) * 8192u + (ln & 3u) * 128u;
+            tch0 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 0, 0);
+            tch1 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 16 * 8192, 0);
+        }
+#endif
         ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, 0u, p);   // (round 1 reads no thread-derived value)
+#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 1
+        asm volatile("" ::"v"(tch0), "v"(tch1));
+#endif
         MI355NTT_STAMPV(1, 2);
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
         MI355NTT_STAMPV(2, -1);
@@ -431,8 +445,30 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         MI355NTT_STAMPV(4, -1);
         wave_transpose_5_to_0(v, lds + wave_s * WAVE_SLICE_WORDS, fresh_lane_id());
         MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
+#if defined(MI355NTT_TOUCH_F) && (MI355NTT_TOUCH_F == 2 || MI355NTT_TOUCH_F == 3)
+        // lab: the same lines touched through the scalar cache at the start of the last round (~12 k cycles before the loads);
+        // MI355NTT_TOUCH_F == 3: the first sixteen chunks only
+        unsigned tsink = 0;
+        if (SPLIT == 0 && ynext < num)
+            touch_lines_scalar<(MI355NTT_TOUCH_F == 3 ? 16 : 32), 8192, 4, 128>(a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N + wave_s * 64u, tsink);
+#endif
         ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
+#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 4
+        // lab: two vector loads behind the round's last twiddle load (nothing is issued behind them before the row stores)
+        u32 tch0 = 0, tch1 = 0;
+        if (SPLIT == 0 && ynext < num) {
+            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N + wave_s * 64u, 32u * 8192u);
+            const u32 ln = fresh_lane_id(), tvoff = (ln >> 2) * 8192u + (ln & 3u) * 128u;
+            tch0 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 0, 0);
+            tch1 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 16 * 8192, 0);
+        }
+#endif
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
+#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 4
+        asm volatile("" ::"v"(tch0), "v"(tch1));
+#elif defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F >= 2
+        touch_wait(tsink);
+#endif
         MI355NTT_STAMPV(5, 4);
 #ifdef MI355NTT_PRIO_FMEM
         MI355NTT_SETPRIO(MI355NTT_PRIO_FMEM);
@@ -661,9 +697,27 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         if (ynext < num)
             wave_preland_rows_half<0>(slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u));
 #endif
+#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
+        // lab: the second column half (the odd 128-byte lines of the wave's 16 KiB) touched through the scalar cache
+        unsigned tsink = 0;
+        if (ynext < num)
+            touch_lines_scalar<64, 256, 1, 128, 128>(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, tsink);
+#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
+        // lab: ... by one vector load behind the eight LDS-direct loads (older than the result stores: inside the counted wait below)
+        u32 tch = 0;
+        if (ynext < num) {
+            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u);
+            tch = __builtin_amdgcn_raw_buffer_load_b32(nrs, fresh_lane_id() * 256u + 128u, 0, 0);
+        }
+#endif
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
         gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
+#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
+        touch_wait(tsink);
+#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
+        asm volatile("" ::"v"(tch));
+#endif
         MI355NTT_STAMP2(it, 5);
 #ifdef MI355NTT_PRIO_IMEM
         MI355NTT_SETPRIO(MI355NTT_PRIO_IMEM);
@@ -776,9 +830,27 @@ k_inverse15_split(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPai
             split_partner_fetch<0>(hrs, slice, wave_s, fresh_lane_id());
             split_partner_fetch<1>(hrs, slice, wave_s, fresh_lane_id());
         }
+#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
+        // lab: the second column half (the odd 128-byte lines of the wave's 16 KiB) touched through the scalar cache
+        unsigned tsink = 0;
+        if (ynext < num)
+            touch_lines_scalar<64, 256, 1, 128, 128>(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, tsink);
+#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
+        // lab: ... by one vector load behind the eight LDS-direct loads (older than the result stores: inside the counted wait below)
+        u32 tch = 0;
+        if (ynext < num) {
+            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u);
+            tch = __builtin_amdgcn_raw_buffer_load_b32(nrs, fresh_lane_id() * 256u + 128u, 0, 0);
+        }
+#endif
         MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
         gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
+#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
+        touch_wait(tsink);
+#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
+        asm volatile("" ::"v"(tch));
+#endif
         MI355NTT_STAMP2(it, 5);
         if constexpr (SPLIT != 0) {
             if (h == 0) {

@@ -24,7 +24,7 @@
 // ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
 // CXXFLAGS then stops the compilation instead of shipping a different kernel.
 #ifndef MI355NTT_LAB
-#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || \
+#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || \
     defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
     defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
     defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \
@@ -748,6 +748,25 @@ __device__ __forceinline__ void wave_read_prelanded_half(u64 (&out)[16], const u
     });
     wave_lds_fence();
 }
+
+// lab (round 5): touch-prefetch of the next polynomial into L2.  gfx950 has no prefetch instruction and no null
+// destination; a scalar load into one SGPR that stays allocated until touch_wait() is the cheapest form that returns nothing to the
+// vector-memory queue (whose in-order return would put an HBM latency in front of every twiddle load issued behind it).  NC chunks
+// CSTRIDE bytes apart, NL lines LSTRIDE bytes apart in each, from byte OFF0 of `base` (wave-uniform).
+template <int NC, int CSTRIDE, int NL, int LSTRIDE, int OFF0 = 0>
+__device__ __forceinline__ void touch_lines_scalar(const void* base, unsigned& sink)
+{
+    const u64 b = reinterpret_cast<u64>(base);
+    const u32 lo = __builtin_amdgcn_readfirstlane(lo32(b)), hi = __builtin_amdgcn_readfirstlane(hi32(b));
+    const u64 sb = ((u64)hi << 32) | lo;
+    unsigned sk = sink;
+    static_for<NC * NL>([&sk, sb](auto ic) {
+        constexpr int i = decltype(ic)::value, off = OFF0 + (i / NL) * CSTRIDE + (i % NL) * LSTRIDE;
+        asm volatile("s_load_dword %0, %1, %2" : "+s"(sk) : "s"(sb), "n"(off));
+    });
+    sink = sk;
+}
+__device__ __forceinline__ void touch_wait(unsigned& sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink)); }
 
 // Both column halves' global loads issued back to back (16 x 16 B per lane in flight), then the two trips through the
 // slice: one exposed memory latency per polynomial instead of two.
