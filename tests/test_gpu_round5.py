@@ -112,3 +112,39 @@ print("DIGEST", hashlib.sha256(f.cpu().numpy().tobytes() + a.cpu().numpy().tobyt
         assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
     assert outs[0] == outs[1]
+
+
+def test_tail_split_under_checked_raw_calls(native, oracle, gpu):
+    """forwardNTT_batch / inverseNTT_batch (ntt_60bit.cuh:608,652) through the reference-signature entry points on a batch that
+    is cut (256 + 44 polynomials): both launch sequences of a checked call carry the guard, so a table rewritten in place sends
+    head AND tail to the literal kernels, and the restored table brings both back."""
+    n, qs, psis, num = 32768, P.Q60, P.PSI60, 256 + 44
+    threads = min(8, os.cpu_count() or 1)
+    prm = oracle.Params(n, qs, psis)
+    mod = native.Moduli(qs)
+    dev = lambda x: native.to_device(np.ascontiguousarray(x))
+    host = lambda t: native.to_host(t).reshape(num, n)
+    native.raw_cache_clear()
+    d_tp, d_ti = dev(prm.psi_tabs), dev(prm.psiinv_tabs)
+    assert native.raw_uses_fast_kernels(n, d_tp, mod) and native.raw_uses_fast_kernels(n, d_ti, mod, inverse=True)
+    a = oracle.synth_batch(n, num, qs, 505).reshape(num, n)
+    want = oracle.forward_batch(a, prm, threads=threads).reshape(num, n)
+    d_a = dev(a)
+    native.forwardNTT_batch(d_a, n, d_tp, num, 4, mod)
+    assert np.array_equal(host(d_a), want)
+    native.inverseNTT_batch(d_a, n, d_ti, num, 4, mod)
+    assert np.array_equal(host(d_a), a)
+    tabs = prm.psi_tabs.copy()
+    tabs[1, 20000] = (int(tabs[1, 20000]) + 5) % qs[1]      # (an entry of the last stage: one butterfly per polynomial of prime 1 changes)
+    d_tp.copy_(dev(tabs).reshape(d_tp.shape))
+    prm2 = oracle.Params(n, qs, psis)
+    prm2.psi_tabs[:] = tabs
+    want2 = oracle.forward_batch(a, prm2, threads=threads).reshape(num, n)
+    assert not np.array_equal(want2[257], want[257])      # (a polynomial of the tail is affected)
+    d_a = dev(a)
+    native.forwardNTT_batch(d_a, n, d_tp, num, 4, mod)
+    assert np.array_equal(host(d_a), want2)
+    d_tp.copy_(dev(prm.psi_tabs).reshape(d_tp.shape))
+    d_a = dev(a)
+    native.forwardNTT_batch(d_a, n, d_tp, num, 4, mod)
+    assert np.array_equal(host(d_a), want)
