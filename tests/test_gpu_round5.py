@@ -148,3 +148,35 @@ def test_tail_split_under_checked_raw_calls(native, oracle, gpu):
     d_a = dev(a)
     native.forwardNTT_batch(d_a, n, d_tp, num, 4, mod)
     assert np.array_equal(host(d_a), want)
+
+
+def test_tail_split_in_a_captured_graph(native, oracle, gpu):
+    """head + tail launch sequences captured into one hipGraph (forward, fused product, inverse on 512 + 60 polynomials) and replayed
+    twice on fresh data: the oracle's words every time."""
+    import torch
+    n, qs, psis, num = 32768, P.Q60, P.PSI60, 512 + 60
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = oracle.synth_batch(n, num, qs, 901).reshape(num, n)
+    b = oracle.synth_batch(n, num, qs, 902).reshape(num, n)
+    d_a, d_b, d_c = native.to_device(a), native.to_device(b), native.to_device(a)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+        ctx.forward_batch(d_b, num)                    # b -> bhat
+        ctx.polymul_batch(d_a, d_b, num)               # a <- INTT(NTT(a) . bhat)
+        ctx.forward_batch(d_c, num)
+        ctx.inverse_batch(d_c, num)                    # round trip
+    sample = _sample(num, [512])
+    for rep in range(2):
+        d_a.copy_(native.to_device(a)); d_b.copy_(native.to_device(b)); d_c.copy_(native.to_device(a))
+        g.replay()
+        torch.cuda.synchronize()
+        A, Bh, C = (native.to_host(t).reshape(num, n) for t in (d_a, d_b, d_c))
+        assert np.array_equal(C, a), rep
+        for y in sample:
+            bh = oracle.forward(b[y], prm, y % 4)
+            assert np.array_equal(Bh[y], bh), (rep, y)
+            prod = oracle.pointwise_batch(oracle.forward(a[y], prm, y % 4), bh, oracle.Params(n, [qs[y % 4]], [psis[y % 4]], tables=False)).reshape(-1)
+            assert np.array_equal(A[y], oracle.inverse(prod, prm, y % 4)), (rep, y)
+    ctx.close()
