@@ -46,6 +46,10 @@ constexpr unsigned kSharedB = 0x80000000u;
 // with kSharedB: bits 8..30 of the division word = polynomials per key group (0: one group); polynomial y then multiplies
 // with bhat[(y / group) * division + y % division] -- the two components of a batch of ciphertexts in one launch
 constexpr unsigned kSharedGroupShift = 8, kDivisionMask = 0xffu;
+// k_inverse15 only: bit 30 of the division word = "this launch streams" -- the batch is several times the memory-side cache
+// (kInvStreamLoadsMin polynomials of 256 KiB = 1 GiB), so the 16-byte row loads carry the non-temporal hint (kernels_fast_impl.cuh,
+// MI355NTT_INV15_AUX_LD; measured there)
+constexpr unsigned kStreamLoads = 0x40000000u, kInvStreamLoadsMin = 4096;
 
 // ---- literal stage-per-launch kernels (kernels_compat.hip) ----
 hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,

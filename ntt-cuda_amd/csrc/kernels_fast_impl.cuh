@@ -278,6 +278,19 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 #ifndef MI355NTT_INV15_AUX_ST
 #define MI355NTT_INV15_AUX_ST 17
 #endif
+// Cache policy of k_inverse15's 16-byte row loads in launches that stream (kStreamLoads in the division word: batches of 4096
+// polynomials = 1 GiB and more; aux bits: 2 = nt).  Round 5 (profiles/r05_streaming_overlap.txt, section 9; shipped library against a build
+// with the default policy, three processes each): non-temporal, inverse launches on their own run 1.8 / 2.4 / 2.3 / 0.8 % faster at 1024 /
+// 2048 / 4096 / 8192 polynomials -- a polynomial is read exactly once, and a line that does not displace the twiddle tables and the
+// result lines in the L2 is worth more than its own residency -- while forward -> inverse pairs, where the inverse reads what the forward
+// launch has just written, LOSE 0.5 / 0.8 / 0.3 % at 1024 / 2048 / 4096 and gain 0.1 % at 8192; sc0 / sc1 change nothing.  Pairs are
+// the common use and the contract's metric, so the hint is confined to the sizes where it costs them nothing measurable.  The forward
+// kernel's column loads lose 1.1 % with the same hint and keep the default, and so do the second operands of the fused product (shared
+// ones are re-read by every workgroup).  Only the load instructions exist twice in the code (wave_load_rows_half, alt).
+#ifndef MI355NTT_INV15_AUX_LD
+#define MI355NTT_INV15_AUX_LD 2
+#endif
+inline unsigned inv15_division_word(unsigned division, unsigned num) { return division | (num >= kInvStreamLoadsMin ? kStreamLoads : 0u); }
 // Order in which k_inverse15's persistent workgroups walk the batch: 1 = from the last polynomial down.  A forward
 // transform is normally followed by an inverse over the same polynomials (and the other way round): walking them in
 // opposite directions makes each kernel start on what the previous one wrote last, i.e. on what is still in the
@@ -646,6 +659,8 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
+    const bool stream_loads = (division & kStreamLoads) != 0;        // (wave-uniform: a kernel argument)
+    division &= ~kStreamLoads;
     // thread-derived values are rebuilt where they are used (wave index in an SGPR, lane index from v_mbcnt), as in
     // k_forward15: kept live across the polynomial loop they are spills in the general-prime instantiations
     unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -659,7 +674,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
     MI355NTT_WGSTAMP(1);
     // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic)
-    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+    wave_load_rows<MI355NTT_INV15_AUX_LD>(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
     [[maybe_unused]] int it = 0;
     MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
@@ -695,7 +710,7 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         // (the exchange ends with a barrier: every slice is dead until this wave's own row staging) the next polynomial's first
         // column half starts its way from memory now and lands in the slice during the last round
         if (ynext < num)
-            wave_preland_rows_half<0>(slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u));
+            wave_preland_rows_half<0, MI355NTT_INV15_AUX_LD>(slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), stream_loads);
 #endif
 #if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
         // lab: the second column half (the odd 128-byte lines of the wave's 16 KiB) touched through the scalar cache
@@ -732,12 +747,12 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
             u64 h[16];
             wave_read_prelanded_half(h, slice);
             static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
-            wave_load_rows_half<1>(h, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+            wave_load_rows_half<1, MI355NTT_INV15_AUX_LD>(h, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
             static_for<16>([&](auto rc) { v[16 + decltype(rc)::value] = h[decltype(rc)::value]; });
         }
 #else
         if (ynext < num)
-            wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+            wave_load_rows<MI355NTT_INV15_AUX_LD>(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
 #endif
         MI355NTT_STAMP2(it, 6);
         if (it < 5) MI355NTT_WGSTAMP(2 + it);
@@ -1160,7 +1175,7 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
 #ifdef MI355NTT_ONLY_HL4N
-    if constexpr (LOGN == 15) k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+    if constexpr (LOGN == 15) k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, inv15_division_word(division, num), base, num);
 #else
     using L = LatGeo<LOGN>;
     if (use_latency_path<LOGN>(num, false)) {
@@ -1175,7 +1190,7 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     dispatch_class(hl, [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
-        if constexpr (LOGN == 15) k_inverse15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        if constexpr (LOGN == 15) k_inverse15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, inv15_division_word(division, num), base, num);
         else k_inverse<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     });
 #endif

@@ -24,7 +24,7 @@
 // ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
 // CXXFLAGS then stops the compilation instead of shipping a different kernel.
 #ifndef MI355NTT_LAB
-#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || \
+#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || defined(MI355NTT_ROWS_AUX_LD) || defined(MI355NTT_INV15_AUX_LD) || \
     defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
     defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
     defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \
@@ -179,6 +179,12 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, u32 bytes)
 #endif
 #ifndef MI355NTT_STREAM_AUX_ST
 #define MI355NTT_STREAM_AUX_ST 0
+#endif
+// ... of the 16-byte row loads alone (the inverse and fused kernels' polynomial loads, wave_load_rows* / wave_preland_rows_half): lab switch
+// of round 5 -- non-temporal row loads speed up inverse launches on their own by 3-4 % at 8192 polynomials and leave forward -> inverse
+// pairs where they were (profiles/r05_streaming_overlap.txt, section 7)
+#ifndef MI355NTT_ROWS_AUX_LD
+#define MI355NTT_ROWS_AUX_LD MI355NTT_STREAM_AUX_LD
 #endif
 __device__ __forceinline__ u64 buf_load_u64(BufRsrc r, u32 voff, u32 soff)
 {
@@ -687,21 +693,29 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
     });
 }
 
-// one column half (CH = 0/1): 16 words of this lane's row into out[0..15]
-template <int CH>
-__device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned)
+template <int CH, int AUX>
+__device__ __forceinline__ void issue_row_loads(v4u32 (&x)[8], BufRsrc src, unsigned voff)
+{
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+#ifdef MI355NTT_ABLATE_LOADK     // timing experiments only (round 5, bound of pre-landing): the first K/2 of the 16 row loads cost nothing
+        if constexpr (8 * CH + k < MI355NTT_ABLATE_LOADK / 2) { x[k] = v4u32{voff, voff, voff, voff}; return; }
+#endif
+        x[k] = __builtin_amdgcn_raw_buffer_load_b128(src, voff, k * 2048u + CH * 128u, AUX);
+    });
+}
+// one column half (CH = 0/1): 16 words of this lane's row into out[0..15].  AUX_ALT: cache-policy bits of the global loads when the
+// (wave-uniform) run-time flag `alt` is set -- only the eight load instructions are issued twice in the code, the rest is shared
+template <int CH, int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+__device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned, bool alt = false)
 {
     const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     v4u32 x[8];
-    static_for<8>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-#ifdef MI355NTT_ABLATE_LOADK     // timing experiments only (round 5, bound of pre-landing): the first K/2 of the 16 row loads cost nothing
-        if constexpr (8 * CH + k < MI355NTT_ABLATE_LOADK / 2) { x[k] = v4u32{lane, sw, lane, sw}; return; }
-#endif
-        x[k] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + CH * 128u, MI355NTT_STREAM_AUX_LD);
-    });
+    if (AUX_ALT != MI355NTT_ROWS_AUX_LD && alt) issue_row_loads<CH, AUX_ALT>(x, src, wave_byte_off + rr * 256u + sw * 16u);
+    else issue_row_loads<CH, MI355NTT_ROWS_AUX_LD>(x, src, wave_byte_off + rr * 256u + sw * 16u);
+    if constexpr (AUX_ALT != MI355NTT_ROWS_AUX_LD) __builtin_amdgcn_sched_barrier(0);     // (a convergent join: keeps the compiler from duplicating the staging code below into both arms)
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4)) = x[k];
@@ -723,17 +737,24 @@ __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, 
 // row 8 k + (L >> 3), slot L & 7 of the staging layout of wave_load_rows_half; the swizzle moves to the global side: the lane fetches
 // piece slot ^ row_swz(row) of its row (still eight whole 128-byte lines per instruction).
 typedef __attribute__((address_space(3))) void* LdsVoidPtr;
-template <int CH>
-__device__ __forceinline__ void wave_preland_rows_half(u64* slice, BufRsrc src)
+template <int CH, int AUX>
+__device__ __forceinline__ void issue_preland_loads(u64* slice, BufRsrc src, unsigned voff_even, unsigned voff_odd)
+{
+    static_for<8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (LdsVoidPtr)(slice + k * 128), 16, (k & 1) ? voff_odd : voff_even, k * 2048u + CH * 128u, 0, AUX);
+    });
+}
+template <int CH, int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+__device__ __forceinline__ void wave_preland_rows_half(u64* slice, BufRsrc src, bool alt = false)
 {
     const unsigned lane = fresh_lane_id();
     const unsigned sw = lane & 7, rr = lane >> 3;
     const unsigned voff_even = rr * 256u + ((sw ^ (rr >> 1)) << 4);       // row_swz(8 k + rr) = 4 (k & 1) | (rr >> 1)
     const unsigned voff_odd = voff_even ^ 64u;
-    static_for<8>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (LdsVoidPtr)(slice + k * 128), 16, (k & 1) ? voff_odd : voff_even, k * 2048u + CH * 128u, 0, MI355NTT_STREAM_AUX_LD);
-    });
+    if (AUX_ALT != MI355NTT_ROWS_AUX_LD && alt) issue_preland_loads<CH, AUX_ALT>(slice, src, voff_even, voff_odd);
+    else issue_preland_loads<CH, MI355NTT_ROWS_AUX_LD>(slice, src, voff_even, voff_odd);
+    if constexpr (AUX_ALT != MI355NTT_ROWS_AUX_LD) __builtin_amdgcn_sched_barrier(0);
 }
 // (the caller has waited for the eight LDS-direct loads with a counted s_waitcnt vmcnt)
 __device__ __forceinline__ void wave_read_prelanded_half(u64 (&out)[16], const u64* slice)
@@ -773,15 +794,17 @@ __device__ __forceinline__ void touch_wait(unsigned& sink) { asm volatile("s_wai
 #ifndef MI355NTT_INV_MERGED_LOADS
 #define MI355NTT_INV_MERGED_LOADS 0
 #endif
-__device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned)
+template <int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+__device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned, bool alt = false)
 {
     const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     v4u32 x[16];
+    (void)alt;                           // (lab form: both halves' loads at the default policy)
     static_for<16>([&](auto ic) {
         constexpr int i = decltype(ic)::value, k = i & 7, ch = i >> 3;
-        x[i] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, MI355NTT_STREAM_AUX_LD);
+        x[i] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, MI355NTT_ROWS_AUX_LD);
     });
     static_for<2>([&](auto cc) {
         constexpr int ch = decltype(cc)::value;
@@ -800,20 +823,21 @@ __device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, 
     });
 }
 
-__device__ __forceinline__ void wave_load_rows(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane)
+template <int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+__device__ __forceinline__ void wave_load_rows(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane, bool alt = false)
 {
 #ifdef MI355NTT_ABLATE_ROWS          // timing experiments only: no row loads (results are wrong)
     static_for<32>([&](auto rc) { v[decltype(rc)::value] = (u64)fresh_lane_id() * 0x9E3779B97F4A7C15ULL + decltype(rc)::value; });
     return;
 #endif
     if constexpr (MI355NTT_INV_MERGED_LOADS) {
-        wave_load_rows_merged(v, slice, src, wave_byte_off, lane);
+        wave_load_rows_merged<AUX_ALT>(v, slice, src, wave_byte_off, lane, alt);
         return;
     }
     u64 h[16];
-    wave_load_rows_half<0>(h, slice, src, wave_byte_off, lane);
+    wave_load_rows_half<0, AUX_ALT>(h, slice, src, wave_byte_off, lane, alt);
     static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
-    wave_load_rows_half<1>(h, slice, src, wave_byte_off, lane);
+    wave_load_rows_half<1, AUX_ALT>(h, slice, src, wave_byte_off, lane, alt);
     static_for<16>([&](auto rc) { v[16 + decltype(rc)::value] = h[decltype(rc)::value]; });
 }
 
