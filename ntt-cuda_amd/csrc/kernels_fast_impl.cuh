@@ -290,6 +290,15 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 #ifndef MI355NTT_INV15_AUX_LD
 #define MI355NTT_INV15_AUX_LD 2
 #endif
+// k_polymul15's second operands arrive through LDS-direct loads (wave_load_rows_half_direct: no VGPRs and no ds_write pass on the way
+// into the slice; -0.1...-0.6 % on its own) and, when every polynomial has its own (read exactly once; operands shared by the batch or by
+// a key group are re-read by every workgroup and keep the default policy), with the non-temporal hint: fused products -3.7 / -1.1 /
+// -1.4 / -1.1 % at 1024 / 2048 / 4096 / 8192 polynomials and -1.5 % at 640 (round 5, tools/probe/invld_ab.py against the previous build,
+// three processes each).  The run-time choice is a branch around eight instructions that define no register; the 62-bit classes, whose
+// fused kernel sits at 128 VGPRs, answer even that with 596 bytes of scratch and keep the default policy.
+#ifndef MI355NTT_MUL15_B_AUX_LD
+#define MI355NTT_MUL15_B_AUX_LD 2
+#endif
 inline unsigned inv15_division_word(unsigned division, unsigned num) { return division | (num >= kInvStreamLoadsMin ? kStreamLoads : 0u); }
 // Order in which k_inverse15's persistent workgroups walk the batch: 1 = from the last polynomial down.  A forward
 // transform is normally followed by an inverse over the same polynomials (and the other way round): walking them in
@@ -747,7 +756,11 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
             u64 h[16];
             wave_read_prelanded_half(h, slice);
             static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
+#ifdef MI355NTT_INV15_HALF1_DIRECT      // lab: the second column half through LDS-direct loads as well
+            wave_load_rows_half_direct<1, MI355NTT_INV15_AUX_LD>(h, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), stream_loads);
+#else
             wave_load_rows_half<1, MI355NTT_INV15_AUX_LD>(h, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
+#endif
             static_for<16>([&](auto rc) { v[16 + decltype(rc)::value] = h[decltype(rc)::value]; });
         }
 #else
@@ -996,12 +1009,12 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         // ---- pointwise product with bhat, streamed 16 words per lane at a time (layout 0 on both sides) ----
         {
             u64 bb[16];
-            wave_load_rows_half<0>(bb, slice, brs, 0u, 0u);
+            wave_load_rows_half_direct<0, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && !sb.on);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[r] = FusedMul<HL, NEAR>::mul(v[r], bb[r], p);
             });
-            wave_load_rows_half<1>(bb, slice, brs, 0u, 0u);
+            wave_load_rows_half_direct<1, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && !sb.on);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[16 + r] = FusedMul<HL, NEAR>::mul(v[16 + r], bb[r], p);

@@ -24,7 +24,7 @@
 // ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
 // CXXFLAGS then stops the compilation instead of shipping a different kernel.
 #ifndef MI355NTT_LAB
-#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || defined(MI355NTT_ROWS_AUX_LD) || defined(MI355NTT_INV15_AUX_LD) || \
+#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || defined(MI355NTT_ROWS_AUX_LD) || defined(MI355NTT_INV15_AUX_LD) || defined(MI355NTT_MUL15_B_AUX_LD) || defined(MI355NTT_INV15_HALF1_DIRECT) || \
     defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
     defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
     defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \
@@ -768,6 +768,20 @@ __device__ __forceinline__ void wave_read_prelanded_half(u64 (&out)[16], const u
         out[2 * m + 1] = pr.y;
     });
     wave_lds_fence();
+}
+
+// One column half through LDS-direct loads end to end: request, wait, read-out -- no VGPRs and no ds_write pass between memory and the
+// slice (wave_load_rows_half moves the same bytes memory -> VGPR -> ds_write_b128 -> slice), and the run-time choice of the cache policy
+// (alt) is a branch around eight instructions that define no register.  The slice must be idle (every earlier LDS access of this wave
+// retired); waits for everything this wave has in the vector-memory queue.
+template <int CH, int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+__device__ __forceinline__ void wave_load_rows_half_direct(u64 (&out)[16], u64* slice, BufRsrc src, bool alt = false)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    wave_preland_rows_half<CH, AUX_ALT>(slice, src, alt);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (hipcc does not order an LDS read behind the LDS-direct load that fills it)
+    wave_read_prelanded_half(out, slice);
 }
 
 // lab (round 5): touch-prefetch of the next polynomial into L2.  gfx950 has no prefetch instruction and no null
