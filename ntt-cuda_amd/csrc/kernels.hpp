@@ -50,6 +50,9 @@ constexpr unsigned kSharedGroupShift = 8, kDivisionMask = 0xffu;
 // (kInvStreamLoadsMin polynomials of 256 KiB = 1 GiB), so the 16-byte row loads carry the non-temporal hint (kernels_fast_impl.cuh,
 // MI355NTT_INV15_AUX_LD; measured there)
 constexpr unsigned kStreamLoads = 0x40000000u, kInvStreamLoadsMin = 4096;
+// k_polymul15, second operands that are NOT shared (with kSharedB bit 30 belongs to the group field): the same bit = "a and bhat together
+// exceed the memory-side cache" -- more than kMulStreamLoadsAbove polynomials -- and the bhat loads carry the non-temporal hint
+constexpr unsigned kMulStreamLoadsAbove = 512;
 
 // ---- literal stage-per-launch kernels (kernels_compat.hip) ----
 hipError_t compat_forward_batch(u64* d_a, unsigned n, const u64* d_tabs, unsigned num, unsigned division, const ModSet& m,

@@ -291,10 +291,12 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
 #define MI355NTT_INV15_AUX_LD 2
 #endif
 // k_polymul15's second operands arrive through LDS-direct loads (wave_load_rows_half_direct: no VGPRs and no ds_write pass on the way
-// into the slice; -0.1...-0.6 % on its own) and, when every polynomial has its own (read exactly once; operands shared by the batch or by
-// a key group are re-read by every workgroup and keep the default policy), with the non-temporal hint: fused products -3.7 / -1.1 /
-// -1.4 / -1.1 % at 1024 / 2048 / 4096 / 8192 polynomials and -1.5 % at 640 (round 5, tools/probe/invld_ab.py against the previous build,
-// three processes each).  The run-time choice is a branch around eight instructions that define no register; the 62-bit classes, whose
+// into the slice; -0.6...-0.9 % at every batch size on its own) and, when every polynomial has its own (read exactly once; operands shared
+// by the batch or by a key group are re-read by every workgroup and keep the default policy) AND a and bhat together exceed the
+// memory-side cache (kStreamLoads: more than 512 polynomials), with the non-temporal hint: fused products -1.5 / -3.7 / -1.1 / -1.4 /
+// -1.1 % at 640 / 1024 / 2048 / 4096 / 8192 polynomials (round 5, tools/probe/invld_ab.py against the previous build, three processes
+// each); on batches the cache holds the hint costs 1-2 % (192 ... 512 polynomials, tools/probe/fused_small_ab.py: the next launch finds
+// less of them there).  The run-time choice is a branch around eight instructions that define no register; the 62-bit classes, whose
 // fused kernel sits at 128 VGPRs, answer even that with 596 bytes of scratch and keep the default policy.
 #ifndef MI355NTT_MUL15_B_AUX_LD
 #define MI355NTT_MUL15_B_AUX_LD 2
@@ -968,6 +970,8 @@ __global__ void __launch_bounds__(1024, 4)
 k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
             const PrimeDev* __restrict__ primes, unsigned division, unsigned num)
 {
+    const bool stream_b = (division & (kSharedB | kStreamLoads)) == kStreamLoads;      // (own second operands, batch beyond the memory-side cache)
+    if (stream_b) division &= ~kStreamLoads;
     const SharedB sb(division);       // (kSharedB: bhat holds `division` polynomials per key group instead of one per polynomial)
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
@@ -1009,12 +1013,12 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         // ---- pointwise product with bhat, streamed 16 words per lane at a time (layout 0 on both sides) ----
         {
             u64 bb[16];
-            wave_load_rows_half_direct<0, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && !sb.on);
+            wave_load_rows_half_direct<0, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && stream_b);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[r] = FusedMul<HL, NEAR>::mul(v[r], bb[r], p);
             });
-            wave_load_rows_half_direct<1, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && !sb.on);
+            wave_load_rows_half_direct<1, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && stream_b);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[16 + r] = FusedMul<HL, NEAR>::mul(v[16 + r], bb[r], p);
@@ -1230,7 +1234,8 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
         if constexpr (LOGN == 15) {
-            k_polymul15<H, NR><<<dim3(persistent_grid<LOGN>(num)), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+            const unsigned dw = division | ((division & kSharedB) == 0 && num > kMulStreamLoadsAbove ? kStreamLoads : 0u);
+            k_polymul15<H, NR><<<dim3(persistent_grid<LOGN>(num)), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, dw, num);
         } else {
             k_polymul<LOGN, H, NR><<<dim3(num), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division);
         }
