@@ -17,7 +17,7 @@ def _sample(num, head_guess):
     ys = {0, 1, num // 2, num - 2, num - 1}
     for h in head_guess:
         ys |= {max(0, h - 1), min(num - 1, h), min(num - 1, h + 1)}
-    return sorted(ys)
+    return sorted(y for y in ys if 0 <= y < num)
 
 
 @pytest.mark.parametrize("primes,num", [(4, 256 + 40), (4, 512 + 100), (3, 512 + 77), (5, 640), (5, 1024 + 33), (4, 256 + 96), (4, 256 + 97), (5, 512 + 98)])
@@ -179,4 +179,52 @@ def test_tail_split_in_a_captured_graph(native, oracle, gpu):
             assert np.array_equal(Bh[y], bh), (rep, y)
             prod = oracle.pointwise_batch(oracle.forward(a[y], prm, y % 4), bh, oracle.Params(n, [qs[y % 4]], [psis[y % 4]], tables=False)).reshape(-1)
             assert np.array_equal(A[y], oracle.inverse(prod, prm, y % 4)), (rep, y)
+    ctx.close()
+
+
+@pytest.mark.parametrize("num", [4095, 4096, 4097])
+def test_inverse_on_both_sides_of_the_streaming_switch(native, oracle, gpu, num):
+    """k_inverse15 reads its rows with the non-temporal hint from 4096 polynomials up (kStreamLoads, kernels.hpp): the words must not
+    depend on the policy -- round trip over the whole batch on the device, sampled polynomials against the oracle."""
+    import torch
+    n, qs, psis = 32768, P.Q60, P.PSI60
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = torch.empty((num, n), dtype=torch.int64, device="cuda:0")
+    ctx.synth_splitmix(a, num, 1)
+    a0 = a.clone()
+    ctx.inverse_batch(a, num)                     # (any canonical words are a valid input)
+    sample = _sample(num, [4096, 2048])
+    got = {y: a[y].cpu().numpy().view(np.uint64) for y in sample}
+    for y in sample:
+        assert np.array_equal(got[y], oracle.inverse(a0[y].cpu().numpy().view(np.uint64), prm, y % 4)), (num, y)
+    ctx.forward_batch(a, num)
+    assert torch.equal(a, a0), num
+    ctx.close()
+
+
+@pytest.mark.parametrize("num", [512, 513, 700])
+def test_fused_product_on_both_sides_of_the_streaming_switch(native, oracle, gpu, num):
+    """k_polymul15 reads own second operands with the non-temporal hint above 512 polynomials; shared ones never (kSharedB)."""
+    import torch
+    n, qs, psis = 32768, P.Q60, P.PSI60
+    prm = oracle.Params(n, qs, psis)
+    ctx = native.NTTContext(n, qs, psis)
+    a = torch.empty((num, n), dtype=torch.int64, device="cuda:0")
+    b = torch.empty((num, n), dtype=torch.int64, device="cuda:0")
+    ctx.synth_splitmix(a, num, 11)
+    ctx.synth_splitmix(b, num, 50011)
+    a0 = a.clone()
+    ctx.forward_batch(b, num)                     # bhat
+    ctx.polymul_batch(a, b, num)
+    # the same product composed of the three steps
+    c = a0.clone()
+    ctx.forward_batch(c, num)
+    ctx.pointwise_mul(c, c, b, num)
+    ctx.inverse_batch(c, num)
+    assert torch.equal(a, c), num
+    for y in _sample(num, [512]):
+        ah = oracle.forward(a0[y].cpu().numpy().view(np.uint64), prm, y % 4)
+        prod = oracle.pointwise_batch(ah, b[y].cpu().numpy().view(np.uint64), oracle.Params(n, [qs[y % 4]], [psis[y % 4]], tables=False)).reshape(-1)
+        assert np.array_equal(a[y].cpu().numpy().view(np.uint64), oracle.inverse(prod, prm, y % 4)), (num, y)
     ctx.close()
