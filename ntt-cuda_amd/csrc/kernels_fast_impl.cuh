@@ -259,6 +259,13 @@ __device__ __forceinline__ void setprio_by_age(unsigned wave_s, int base)
 #ifndef MI355NTT_STAGGER_MUL
 #define MI355NTT_STAGGER_MUL 0
 #endif
+// Round 5 (tools/probe/fused_small_ab.py, two processes each): the fused kernel with 2 units when a workgroup walks more than one polynomial --
+// 448 / 512 / 576 / 640 / 704 / 768 / 896 polynomials: -3.6 / -7.7 / -7.0 / -7.2 / -5.4 / -2.8 / -5.9 % per launch, 1024: +-0, 1280 ... 8192:
+// -0.5 ... -1.3 % (1 unit: about two thirds of that; 4 units: +4 % at 640 and 1024).  640 is the batched BFV encryption's launch (64
+// ciphertexts on 4 + 1 primes).
+#ifndef MI355NTT_STAGGER_MUL_MULTI
+#define MI355NTT_STAGGER_MUL_MULTI 2
+#endif
 template <int UNITS, int UNITS_MULTI = UNITS>
 __device__ __forceinline__ void stagger_start(bool multi = false)
 {
@@ -984,7 +991,7 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
-    stagger_start<MI355NTT_STAGGER_MUL>();
+    stagger_start<MI355NTT_STAGGER_MUL, MI355NTT_STAGGER_MUL_MULTI>(num > gridDim.x);
     load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)y * G::N, fresh_t());
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's

@@ -24,7 +24,7 @@
 // ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
 // CXXFLAGS then stops the compilation instead of shipping a different kernel.
 #ifndef MI355NTT_LAB
-#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || defined(MI355NTT_ROWS_AUX_LD) || defined(MI355NTT_INV15_AUX_LD) || defined(MI355NTT_MUL15_B_AUX_LD) || defined(MI355NTT_INV15_HALF1_DIRECT) || \
+#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || defined(MI355NTT_ROWS_AUX_LD) || defined(MI355NTT_INV15_AUX_LD) || defined(MI355NTT_MUL15_B_AUX_LD) || defined(MI355NTT_INV15_HALF1_DIRECT) || defined(MI355NTT_STAGGER_MUL_MULTI) || \
     defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
     defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
     defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \

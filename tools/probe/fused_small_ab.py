@@ -12,7 +12,7 @@ n = 32768
 ctx = ntt.NTTContext(n, P.Q60, P.PSI60)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 out = []
-for num in (100, 128, 192, 256, 320, 384, 512, 768):
+for num in [int(x) for x in os.environ.get("MI355NTT_PROBE_SIZES", "100,128,192,256,320,384,512,768").split(",")]:
     a = torch.empty((num, n), dtype=torch.int64, device=dev); ctx.synth_splitmix(a, num, 5)
     b = a.clone(); ctx.forward_batch(b, num)
     def rate(fn, reps=400):
