@@ -131,6 +131,9 @@ def parse():
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.5,
+                    help="untimed, time-based pre-warm: back-to-back steps for at least this long before the W warm-up steps (the SMU "
+                         "takes about a second of load to settle the clocks under the package-power limit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU for a dry run)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time scatter -> forward+inverse -> gather from a rank-0-resident batch (SURVEY.md 8(e), report 2)")
@@ -474,11 +477,23 @@ def main():
         step()
     torch.cuda.synchronize()
     cold_pairs_per_s = batch * 20 / (time.perf_counter() - t_c)
-    # The chip needs tens of milliseconds of load to settle its clocks (measured: 2.52 M pairs/s over a cold 20-step
-    # region vs 2.80 M over 200 steps).  A fixed untimed pre-warm keeps short --steps runs from timing the ramp; the
-    # W warm-up steps then flow straight into the timed region (no idle gap).
-    for _ in range(150):
-        step()
+    # The SMU needs about a SECOND of load to settle the clocks under the package-power limit (round 5: the driver's 6.8 ms region,
+    # 60 ms after the first launch behind a step-counted pre-warm, read 3.00 M pairs/s while the same process sustained 3.12-3.14 M
+    # seconds later).  The untimed pre-warm is therefore time-based: back-to-back steps for at least --prewarm-seconds of wall clock,
+    # queued in chunks with at most two chunks in flight (the GPU never runs dry, the queue never grows), then the W warm-up steps,
+    # flowing straight into the timed region.  What is timed does not change: exactly K steps between barrier + synchronize.
+    prewarm_steps, chunk_steps = 0, 100
+    pw_ev = []
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < args.prewarm_seconds:
+        for _ in range(chunk_steps):
+            step()
+        prewarm_steps += chunk_steps
+        pw_ev.append(torch.cuda.Event())
+        pw_ev[-1].record()
+        if len(pw_ev) >= 3:
+            pw_ev[-3].synchronize()
+    prewarm_s = time.perf_counter() - t_pw
     for _ in range(args.warmup):
         step()
 
@@ -493,10 +508,13 @@ def main():
     e_end.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_min = elapsed
     if use_pg:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        # MAX over ranks of the elapsed time (the contract's clock) and, in the same collective, of its negative: the fastest rank's
+        # time -- a straggler GPU shows in the one line as per_rank_pairs_per_s.min well below .max
+        tt = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, elapsed_min = float(tt[0].item()), -float(tt[1].item())
     step_ms_events = e_beg.elapsed_time(e_end) / args.steps
     assert torch.equal(a, a0)
 
@@ -536,6 +554,10 @@ def main():
     assert torch.equal(a, a0)
 
     pairs_per_s = world * batch * args.steps / elapsed
+    rounds_median = world * batch / (round_ms[ROUNDS // 2] * 1e-3)
+    # settled: the contract's region agrees with the median of the 20 rounds timed right behind it within 1.5 % -- the timed
+    # region was read at the clocks the chip holds under this load, not on the way there
+    settled = abs(pairs_per_s - rounds_median) / rounds_median < 0.015
     dom_name, dom_ms = ("k_forward15", fwd_ms) if fwd_ms >= inv_ms else ("k_inverse15", inv_ms)
     alg_bytes = batch * BYTES_PER_TRANSFORM                       # per launch of either kernel
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9                  # GB/s
@@ -596,6 +618,10 @@ def main():
                                             "note": "rocprofv3 --kernel-trace --stats of bench.py, another run on another box; `frac` above is this run's HIP-event time"}
                                            if rp_ms else None),
                      "pair_frac_of_hbm_peak": pairs_per_s / world * 2 * BYTES_PER_TRANSFORM / HBM_PEAK,
+                     # (repeated here because the driver's parsed copy of the line keeps `roofline` whole: the same step timed as 20 rounds
+                     # right behind the contract's region, and whether `value` agrees with their median within 1.5 %)
+                     "settled": settled,
+                     "rounds_pairs_per_s": {"median": rounds_median, "best": world * batch / (round_ms[0] * 1e-3), "worst": world * batch / (round_ms[-1] * 1e-3)},
                      "valu_ceiling_transforms_per_s": valu_ceiling,
                      "frac_of_valu_ceiling": (batch / (dom_ms * 1e-3) / valu_ceiling) if valu_ceiling else None,
                      "valu_ceiling_pairs_per_s": valu_pairs,
@@ -608,8 +634,12 @@ def main():
                                             "of this run.  NOT reachable together with the memory traffic: the package sits at its power cap "
                                             "(extras.power_sustained, profiles/r04_power_cap_and_overlap.txt)" % (os.path.relpath(vpath, ROOT) if vpath else None)},
         "kernel_ms": {"k_forward15": fwd_ms, "k_inverse15": inv_ms, "step_by_events": step_ms_events},
+        "settled": settled,
+        "per_rank_pairs_per_s": {"min": batch * args.steps / elapsed, "max": batch * args.steps / elapsed_min,
+                                 "what": "slowest and fastest rank over the same K steps (value = world x batch x K / the slowest rank's time)"},
+        "prewarm": {"seconds": prewarm_s, "steps": prewarm_steps, "how": "untimed, time-based: chunks of %d steps back to back, at most two chunks queued, until --prewarm-seconds of wall clock have passed; then the W warm-up steps" % chunk_steps},
         "rounds": {"what": "%d rounds of %d forward+inverse steps each, queued back to back, HIP events between rounds (BASELINE.md 2)" % (ROUNDS, ROUND_STEPS),
-                   "pairs_per_s_median": world * batch / (round_ms[ROUNDS // 2] * 1e-3), "pairs_per_s_best": world * batch / (round_ms[0] * 1e-3),
+                   "pairs_per_s_median": rounds_median, "pairs_per_s_best": world * batch / (round_ms[0] * 1e-3),
                    "pairs_per_s_worst": world * batch / (round_ms[-1] * 1e-3),
                    "ms_per_step_median": round_ms[ROUNDS // 2], "ms_per_step_min": round_ms[0], "ms_per_step_max": round_ms[-1],
                    "scope": "this rank" if world > 1 else "the GPU"},
@@ -976,15 +1006,26 @@ def main():
     # after MI355NTT_BENCH_TAIL_TIMEOUT seconds (default 180) rank 0 prints the line it has -- `value` is complete at this point --
     # with the reason in `end_to_end`, and every rank leaves.
     tail_timer = None
+    tail_lock, tail_state = None, {"printed": False}
     if world > 1:
         import threading
+        tail_lock = threading.Lock()
+        # the contract line as it stands NOW (`value` is complete), serialised before the timer is armed: the timer thread never walks
+        # the live dictionary the main thread is still writing to, and exactly one of the two threads prints
+        snapshot = dict(out, cpu_baseline=None,
+                        end_to_end={"error": "the tail of the run (end-to-end leg / process-group teardown) did not finish in time; the line was printed without it"},
+                        tail_timeout=True)
+        snapshot_line = json.dumps(snapshot)
 
         def _bail():
-            if rank == 0:
-                out.setdefault("end_to_end", {"error": "the tail of the run (end-to-end leg / process-group teardown) did not finish in time; the line was printed without it"})
-                out["cpu_baseline"] = None
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            with tail_lock:
+                if tail_state["printed"]:
+                    return
+                tail_state["printed"] = True
+                if rank == 0:
+                    print(snapshot_line, flush=True)
+            # rank 0 has a valid contract line (rc 0); the other ranks report the timeout through their exit code, so a launcher sees it
+            os._exit(0 if rank == 0 else 3)
 
         tail_timer = threading.Timer(float(os.environ.get("MI355NTT_BENCH_TAIL_TIMEOUT", "180")), _bail)
         tail_timer.daemon = True
@@ -1027,6 +1068,10 @@ def main():
         dist.destroy_process_group()
     if tail_timer is not None:
         tail_timer.cancel()
+        with tail_lock:
+            if tail_state["printed"]:        # the timer fired between the last collective and the cancel: its line stands
+                return
+            tail_state["printed"] = True
     if rank == 0:
         # rank 0's host cores, after the timed region and after the process group is gone; at N = 1 only (the contract asks for it there:
         # at N > 1 the other ranks' processes would share the cores with it, and the scaling runs need not pay 20 s of CPU work each)

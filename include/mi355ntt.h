@@ -79,16 +79,15 @@ int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt
  * what the reference's kernels print whenever its single-subtraction Barrett is exact for the modulus
  * (mi355ntt_barrett_is_exact: every modulus the reference ships, every q = 2^k - d with d^2 << 2^k).  For the rare
  * other primes (e.g. 68719230977, the second prime of decryption_test.cu) the reference occasionally returns q + r or,
- * one butterfly later, a wrong residue; the polynomials of such a prime therefore run the literal stage-per-launch
- * kernels (same words as the reference, ~4x slower) unless MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES is passed to
- * mi355ntt_ctx_create_ex, which selects the exact kernels regardless.  The routing is per prime: in a context that mixes both
- * kinds (the reference's own decryption_test.cu set: primes 0 and 2 exact, prime 1 not) only the inexact primes' polynomials take
- * the literal kernels -- each call gathers them into a buffer the context owns (allocated at creation: no allocation at call
- * time), the throughput kernels transform the batch, the literal kernels the gathered rows, which are copied back; calls on
- * different streams take turns on that buffer in stream order (an event, no host synchronisation, recorded on every way out of the
- * call, errors included).  A call on a CAPTURING stream cannot join that hand-over, so it runs the literal kernels for all of its
- * primes in place (the same words, no shared buffer): a replayed graph never touches the gather buffer.  n = 65536 contexts with an
- * inexact prime stay literal as a whole.
+ * one butterfly later, a wrong residue.  A context that holds such a prime therefore returns the reference's own words: its
+ * transforms run the single-pass kernels in arithmetic class 0 -- singleBarrett with its one conditional subtraction written
+ * out literally (ntt_60bit.cuh:44-61), the value carried from stage to stage exactly as the reference's memory carries it
+ * (:199-222, :232-264), a halving in every inverse stage -- one read and one write of memory per transform, in place, for every
+ * prime of the context (for the exact ones the literal words ARE the exact transform's), at every batch size and under stream
+ * capture like any other call (round 6; until round 5 these polynomials went through stage-per-launch kernels and a gather
+ * buffer).  MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES passed to mi355ntt_ctx_create_ex selects the exact (lazy-arithmetic) kernels
+ * regardless.  n = 65536 contexts with an inexact prime run the literal stage-per-launch kernels (the reference's dispatch ends at
+ * n = 32768, ntt_60bit.cuh:316-347).
  * ---------------------------------------------------------------------------------------------- */
 #define MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES 1u
 int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
@@ -96,13 +95,14 @@ int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
 int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes,
                            const mi355ntt_u64* q, const mi355ntt_u64* psi, int device, unsigned flags);
 int mi355ntt_ctx_destroy(mi355ntt_ctx* ctx);
-/* 0: every prime on the throughput kernels; 1: the whole context on the literal (reference-arithmetic) kernels; 2: per-prime
- * routing, see above */
+/* 0: exact (lazy-arithmetic) kernels; 1: every prime is Barrett-inexact -- literal (reference-arithmetic) kernels; 2: some primes
+ * are -- the same literal kernels for the whole context, see above */
 int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* ctx);
 /* diagnostic: the arithmetic class the throughput kernels of this context were selected by -- bits 0-3: headroom = min over the
  * primes of (64 - bit length), capped at 6 (values stay below 2^headroom q between partial reductions); bit 4: every prime is
  * "near 2^k" (q = 2^k - d with d < 2^24, 2^(64-k) d + 2 d < 2^k and 2 d^2 + 3 d < 2^k: the 3-instruction fold replaces the general
- * partial reduction).  tests/test_gpu_fuzz_moduli.py recomputes it for moduli drawn on both sides of every threshold. */
+ * partial reduction).  0: the literal-arithmetic class of a context with a Barrett-inexact prime.  tests/test_gpu_fuzz_moduli.py
+ * recomputes it for moduli drawn on both sides of every threshold. */
 int mi355ntt_ctx_kernel_class(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_n(const mi355ntt_ctx* ctx);
 unsigned mi355ntt_ctx_num_primes(const mi355ntt_ctx* ctx);

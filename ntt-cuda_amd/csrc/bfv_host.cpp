@@ -33,8 +33,14 @@ int bfv_bootstrap(BfvParams* out, unsigned n, unsigned R, const u64* q, u64 t, u
     p.mu_gamma = barrett_mu(gamma, gbits);         // demo.cu:218-226
     p.gamma_div_2 = gamma >> 1;                    // demo.cu:94
     p.m64_gamma = ~0ULL / gamma;
+    // Lazy summation mod gamma in k_decrypt_round: each Barrett product is below 2 gamma ONLY while its operand val < q_i stays
+    // below 2^gamma_bits (Algorithm 7's quotient estimate is then at most two short).  With a q_i wider than gamma the
+    // remainder can reach about val + 3 gamma and several terms overflow the 64-bit accumulator where the reference's per-term
+    // `% gamma` (poly_arithmetic.cuh:252) never does: such parameter sets keep the per-term reduction (lazy = 1).
     p.lazy_gamma = (unsigned)((~0ULL - gamma) / (2 * (u128)gamma));      // (>= 1 for gamma < 2^62)
     if (p.lazy_gamma < 1) p.lazy_gamma = 1;
+    for (unsigned i = 0; i + 1 < R; i++)
+        if (bit_length(q[i]) > gbits) p.lazy_gamma = 1;
     p.q_last = q[R - 1];
     p.half_q_last = p.q_last >> 1;
     const unsigned r = p.r;

@@ -46,22 +46,18 @@ struct mi355ntt_ctx {
     u64* d_psi = nullptr;        // [P][n]  psi^bitrev(i)      (reference format, demo.cu:188-196)
     u64* d_psiinv = nullptr;     // [P][n]  psi^-bitrev(i)
     FastTables fast;             // tables of the throughput kernels (kernels_fast.hip)
-    bool literal = false;        // every prime is Barrett-inexact (or n = 2^16 with one that is) and the caller did not ask for exact
-                                 // results: transforms run the stage-per-launch kernels with the reference's arithmetic
-    // Per-prime routing (round 4).  inexact_mask: bit i = prime i is not barrett_exact (and no MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES).
-    // A context with SOME such primes is `mixed`: the polynomials of those primes run the literal kernels, everything else the
-    // throughput kernels -- the reference's words either way.  The literal share of a call goes through a gather buffer
-    // (rows_per_prime rows per inexact prime, allocated with the context); calls take turns on it in stream order (event `last`).
+    // Barrett-inexact primes (hostparams.cpp, barrett_single_subtraction_exact) without MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES: the
+    // reference's single-subtraction Barrett leaves q + r now and then for such a modulus, so the transforms of this context must
+    // return the reference's own words, not the exact transform's.  inexact_mask: bit i = prime i is such a prime.
+    //   literal        -- inexact_mask != 0: every transform of the context runs literal arithmetic.  Up to n = 2^15 that is kernel
+    //                     class HL_LIT of the single-pass kernels (round 6: one read and one write per transform, every prime of the
+    //                     context -- for the exact ones the literal words ARE the exact transform's; no gather buffer, no per-prime
+    //                     routing, nothing special under stream capture);
+    //   literal_stages -- ... at n = 2^16 (beyond the reference's dispatch and the single-pass kernels): the stage-per-launch kernels
+    //                     of kernels_compat.hip;
+    //   mixed          -- some, not all, primes inexact (reported by mi355ntt_ctx_uses_literal_kernels as 2; routing as `literal`).
+    bool literal = false, literal_stages = false, mixed = false;
     unsigned inexact_mask = 0;
-    bool mixed = false;
-    struct Mixed {
-        u64* d = nullptr;
-        unsigned rows_per_prime = 0;
-        hipEvent_t last = nullptr;
-        bool used = false;
-        std::mutex m;
-    };
-    mutable Mixed mix;
     // n = 2^16 (beyond the reference's dispatch): stage 1 splits the transform into two independent half-size ones whose
     // stage `L` reads table entries [2L + h L, 2L + (h + 1) L) -- an ordinary 2^15 transform on a derived table.  `fast`
     // then holds 2 P "virtual primes" (2 i + h) for n/2, polynomial y's half h is virtual polynomial 2 y + h.
@@ -80,115 +76,32 @@ static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
     return r;
 }
 
-// residues r < division whose prime (base + r) is Barrett-inexact in a mixed context
-static unsigned inexact_residues(const mi355ntt_ctx* c, unsigned division, unsigned base)
-{
-    base &= ~kGuardBit;              // (checked raw calls carry the guard flag in the prime base, kernels.hpp)
-    return c->mixed ? (c->inexact_mask >> base) & ((division >= 32 ? 0u : (1u << division)) - 1u) : 0u;
-}
-
-// Mixed context, a call that touches both kinds of primes: the batch is walked in chunks of rows_per_prime groups of `division`
-// polynomials.  Per chunk: the rows of the inexact primes are gathered into the context's buffer (strided device-to-device copies),
-// the throughput kernels transform the whole chunk in place (their result for the gathered rows is discarded), the literal kernels
-// transform the gathered rows with the reference's arithmetic, and those rows are copied back over the chunk.  Everything is
-// enqueued on `s`; another stream's mixed call on the same context waits for this one's last event before it touches the buffer.
-static hipError_t run_mixed(const mi355ntt_ctx* c, bool inverse, u64* d_a, unsigned num, unsigned division, unsigned base, unsigned sub, hipStream_t s)
-{
-    // (a capturing stream cannot take part in the event hand-over -- an event recorded outside the capture cannot be waited for inside
-    // it, and one recorded inside means nothing outside -- so a replayed graph would share the gather buffer with other streams' calls
-    // unordered.  Under capture the whole call therefore runs the literal kernels in place on d_a: the reference's words for every
-    // prime (for the exact ones they ARE the throughput kernels' words), no shared buffer)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-        // (inside a checked raw call -- raw_run sends captured mixed calls to the literal kernels itself, so this is belt and braces --
-        // the literal kernels run under the inverted guard pair: only when the caller's table is the context's; otherwise raw_run's
-        // own fallback leg transforms the data with the caller's table)
-        const unsigned pbc = base & ~kGuardBit;
-        const unsigned* g = (base & kGuardBit) ? static_cast<const unsigned*>(c->fast.d_primes_alloc) + 2 : nullptr;
-        const u64* t = (inverse ? c->d_psiinv : c->d_psi) + (size_t)pbc * c->n;
-        return inverse ? compat_inverse_batch(d_a, c->n, t, num, division, mods_from(c, pbc, division), s, g)
-                       : compat_forward_batch(d_a, c->n, t, num, division, mods_from(c, pbc, division), s, g);
-    }
-    // Checked raw calls (base carries kGuardBit; raw_run has compared the caller's table with the context's on the device): the
-    // throughput kernels skip themselves when the tables differ, and so must the literal kernels on the gathered rows -- they run
-    // under the INVERTED guard pair (words 2, 3 of the guard record, compat_guard_invert); the copies around them move untouched
-    // rows back where they came from, and raw_run's own fallback leg then transforms everything with the caller's table.
-    const unsigned pb = base & ~kGuardBit;
-    const unsigned* lit_guard = (base & kGuardBit) ? static_cast<const unsigned*>(c->fast.d_primes_alloc) + 2 : nullptr;
-    mi355ntt_ctx::Mixed& mx = c->mix;
-    std::lock_guard<std::mutex> lock(mx.m);
-    hipError_t e;
-    if (mx.used && (e = hipStreamWaitEvent(s, mx.last, 0)) != hipSuccess) return e;         // (nothing enqueued yet)
-    // From here on work that reads or writes the gather buffer may sit on `s`: whatever happens, the next stream's call must wait for
-    // it.  `leave` records the hand-over event (or, if even that fails, drains the stream) on every way out, error or not.
-    auto leave = [&](hipError_t rc) {
-        mx.used = (hipEventRecord(mx.last, s) == hipSuccess);
-        if (!mx.used) (void)hipStreamSynchronize(s);
-        return rc;
-    };
-    const unsigned G = mx.rows_per_prime;
-    const size_t row = (size_t)c->n * sizeof(u64);
-    const u64* tabs = inverse ? c->d_psiinv : c->d_psi;
-    for (unsigned y0 = 0; y0 < num; y0 += G * division) {
-        const unsigned cnt = num - y0 < G * division ? num - y0 : G * division;
-        u64* chunk = d_a + (size_t)y0 * c->n;
-        unsigned slot = 0;
-        for (unsigned r = 0; r < division; r++) {
-            if (!((sub >> r) & 1u)) continue;
-            const unsigned rows = cnt > r ? (cnt - r + division - 1) / division : 0;
-            if (rows && (e = hipMemcpy2DAsync(mx.d + (size_t)slot * G * c->n, row, chunk + (size_t)r * c->n, division * row, row, rows,
-                                              hipMemcpyDeviceToDevice, s)) != hipSuccess) return leave(e);
-            slot++;
-        }
-        e = inverse ? fast_inverse_batch(c->fast, chunk, cnt, division, base, s) : fast_forward_batch(c->fast, chunk, cnt, division, base, s);
-        if (e != hipSuccess) return leave(e);
-        slot = 0;
-        for (unsigned r = 0; r < division; r++) {
-            if (!((sub >> r) & 1u)) continue;
-            const unsigned rows = cnt > r ? (cnt - r + division - 1) / division : 0;
-            u64* buf = mx.d + (size_t)slot * G * c->n;
-            slot++;
-            if (!rows) continue;
-            const ModSet m1 = mods_from(c, pb + r, 1);
-            e = inverse ? compat_inverse_batch(buf, c->n, tabs + (size_t)(pb + r) * c->n, rows, 1, m1, s, lit_guard)
-                        : compat_forward_batch(buf, c->n, tabs + (size_t)(pb + r) * c->n, rows, 1, m1, s, lit_guard);
-            if (e != hipSuccess) return leave(e);
-            if ((e = hipMemcpy2DAsync(chunk + (size_t)r * c->n, division * row, buf, row, row, rows, hipMemcpyDeviceToDevice, s)) != hipSuccess) return leave(e);
-        }
-    }
-    return leave(hipSuccess);
-}
-
+// `base`: first prime of the call; checked raw calls carry kGuardBit in it (kernels.hpp) -- the throughput kernels strip it, the
+// table / modulus indexing of the stage-launch legs below uses the plain index pb.
 static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
-    if (const unsigned sub = inexact_residues(c, division, base)) {
-        if (sub == (1u << division) - 1u) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
-        return run_mixed(c, false, d_a, num, division, base, sub, s);
-    }
-    if (c->literal) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+    const unsigned pb = base & ~kGuardBit;
+    if (c->literal_stages) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)pb * c->n, num, division, mods_from(c, pb, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides in the loads of the lower halves' launch (1.5 passes over memory instead of 2)
         if (fast_forward_split16_ok(c->fast, num)) return fast_forward_split16(c->fast, d_a, num, division, base, s);
-        hipError_t e = compat_ct_stage(d_a, c->n, c->d_psi + (size_t)base * c->n, 1, num, division, mods_from(c, base, division), s);
+        hipError_t e = compat_ct_stage(d_a, c->n, c->d_psi + (size_t)pb * c->n, 1, num, division, mods_from(c, pb, division), s);
         if (e != hipSuccess) return e;
         return fast_forward_batch(c->fast, d_a, 2 * num, 2 * division, 2 * base, s);
     }
-    return fast_forward_batch(c->fast, d_a, num, division, base, s);
+    return fast_forward_batch(c->fast, d_a, num, division, base, s);      // (literal contexts up to n = 2^15: kernel class HL_LIT)
 }
 
 static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
-    if (const unsigned sub = inexact_residues(c, division, base)) {
-        if (sub == (1u << division) - 1u) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
-        return run_mixed(c, true, d_a, num, division, base, sub, s);
-    }
-    if (c->literal) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)base * c->n, num, division, mods_from(c, base, division), s);
+    const unsigned pb = base & ~kGuardBit;
+    if (c->literal_stages) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)pb * c->n, num, division, mods_from(c, pb, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides behind the lower halves' last round (1.5 passes over memory instead of 2)
         if (fast_inverse_split16_ok(c->fast, num, false)) return fast_inverse_split16(c->fast, d_a, num, division, base, s);
         hipError_t e = fast_inverse_batch(c->fast, d_a, 2 * num, 2 * division, 2 * base, s);
         if (e != hipSuccess) return e;
-        return compat_gs_stage(d_a, c->n, c->d_psiinv + (size_t)base * c->n, 1, num, division, mods_from(c, base, division), s);
+        return compat_gs_stage(d_a, c->n, c->d_psiinv + (size_t)pb * c->n, 1, num, division, mods_from(c, pb, division), s);
     }
     return fast_inverse_batch(c->fast, d_a, num, division, base, s);
 }
@@ -271,7 +184,7 @@ int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes, con
     return mi355ntt_ctx_create_ex(out, n, num_primes, q, psi, device, 0);
 }
 
-int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* c) { return !c ? 0 : c->literal ? 1 : c->mixed ? 2 : 0; }
+int mi355ntt_ctx_uses_literal_kernels(const mi355ntt_ctx* c) { return !c ? 0 : c->mixed ? 2 : c->literal ? 1 : 0; }
 int mi355ntt_ctx_kernel_class(const mi355ntt_ctx* c) { return !c ? MI355NTT_EINVAL : c->fast.hl; }
 
 int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, const mi355ntt_u64* q, const mi355ntt_u64* psi,
@@ -301,11 +214,10 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
         c->mods.k[i] = c->prime[i].k;
         if (!c->prime[i].barrett_exact && !(flags & MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES)) c->inexact_mask |= 1u << i;
     }
-    // every prime inexact -> the whole context runs the literal kernels; some -> per-prime routing (n = 2^16: its split path has no
-    // mixed form, the whole context stays literal as before)
     if (c->inexact_mask) {
-        if (c->inexact_mask == (num_primes >= 32 ? ~0u : (1u << num_primes) - 1u) || n == 65536) c->literal = true;
-        else c->mixed = true;
+        c->literal = true;
+        c->literal_stages = (n == 65536);
+        c->mixed = !c->literal_stages && c->inexact_mask != (num_primes >= 32 ? ~0u : (1u << num_primes) - 1u);
     }
 
     auto fail = [&](int code) {
@@ -355,16 +267,8 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
         e = fast_tables_create(&c->fast, h_n, 2 * num_primes, vprime, vp.data(), vi.data(), nullptr, nullptr, split_fwd, split_inv);
         c->split16 = (e == hipSuccess);
     } else {
-        e = fast_tables_create(&c->fast, n, num_primes, c->prime, hp.data(), hi.data(), c->d_psi, c->d_psiinv);
-    }
-    if (e == hipSuccess && c->mixed) {
-        // the gather buffer of the literal share: at most 32 MiB, 16 .. 256 groups per chunk
-        const unsigned bad = (unsigned)__builtin_popcount(c->inexact_mask);
-        size_t rows = ((size_t)32 << 20) / ((size_t)n * sizeof(u64) * bad);
-        rows = rows < 16 ? 16 : rows > 256 ? 256 : rows;
-        c->mix.rows_per_prime = (unsigned)rows;
-        e = hipMalloc((void**)&c->mix.d, rows * bad * n * sizeof(u64));
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->mix.last, hipEventDisableTiming);
+        e = fast_tables_create(&c->fast, n, num_primes, c->prime, hp.data(), hi.data(), c->d_psi, c->d_psiinv, nullptr, nullptr,
+                               c->literal && !c->literal_stages);
     }
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
@@ -380,8 +284,6 @@ int mi355ntt_ctx_destroy(mi355ntt_ctx* c)
     DeviceScope scope(c->device);
     if (c->d_psi) (void)hipFree(c->d_psi);
     if (c->d_psiinv) (void)hipFree(c->d_psiinv);
-    if (c->mix.d) (void)hipFree(c->mix.d);
-    if (c->mix.last) (void)hipEventDestroy(c->mix.last);
     fast_tables_destroy(&c->fast);
     delete c;
     return MI355NTT_OK;
@@ -495,7 +397,7 @@ int mi355ntt_polymul_batch(const mi355ntt_ctx* c, mi355ntt_u64* d_a, const mi355
         HIP_TRY(fast_inverse_split16(c->fast, d_a, num, division, 0, (hipStream_t)s, d_bhat));
         return MI355NTT_OK;
     }
-    if (c->literal || c->mixed || c->split16) {   // the reference's own sequence (bfv_encryption.cuh:268-271), three calls
+    if (c->literal_stages || c->split16) {   // the reference's own sequence (bfv_encryption.cuh:268-271), three calls
         HIP_TRY(run_forward(c, d_a, num, division, 0, (hipStream_t)s));
         HIP_TRY(compat_pointwise(d_a, d_a, d_bhat, c->n, num, division, mods_from(c, 0, division), (hipStream_t)s));
         HIP_TRY(run_inverse(c, d_a, num, division, 0, (hipStream_t)s));
@@ -513,7 +415,7 @@ int mi355ntt_polymul_batch_shared(const mi355ntt_ctx* c, mi355ntt_u64* d_a, cons
     if (!d_bhat || (group && group % division) || group >= (1u << 23)) return MI355NTT_EINVAL;
     if (num == 0) return MI355NTT_OK;
     ON_CTX_DEVICE(c);
-    if (!c->literal && !c->mixed && !c->split16) {
+    if (!c->literal_stages && !c->split16) {
         const hipError_t e = fast_polymul_batch(c->fast, d_a, d_bhat, num, division, (hipStream_t)s, true, group);
         if (e == hipSuccess) return MI355NTT_OK;
         if (e != hipErrorNotSupported) HIP_TRY(e);
@@ -682,7 +584,7 @@ mi355ntt_ctx* raw_derive(int device, unsigned n, unsigned division, bool inverse
     mi355ntt_ctx* c = nullptr;
     if (mi355ntt_ctx_create_ex(&c, n, division, q, root, device, 0) != MI355NTT_OK || !c) return nullptr;
     bool same = false;
-    if (!c->literal) {
+    if (!c->literal_stages) {
         unsigned* d_flag = nullptr;
         unsigned h_flag = 1;
         if (hipMalloc((void**)&d_flag, sizeof(unsigned)) == hipSuccess) {
@@ -751,21 +653,15 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
                    hipStream_t s)
 {
     const mi355ntt_ctx* c = e ? e->ctx : nullptr;
-    if (!c || (c->split16 && !e->trusted))
-        return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
-    if (c->mixed && inexact_residues(c, division, 0) == (division >= 32 ? ~0u : (1u << division) - 1u))      // nothing for the throughput kernels
+    if (!c || c->literal_stages || (c->split16 && !e->trusted))
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (e->trusted) return inverse ? run_inverse(c, d_a, num, division, 0, s) : run_forward(c, d_a, num, division, 0, s);
     hipError_t err;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (c->mixed && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)           // (no gather buffer under capture)
-        return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (!e->ev && (err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming)) != hipSuccess) return err;
     if (e->used && e->last_stream != s && (err = hipStreamWaitEvent(s, e->ev, 0)) != hipSuccess) return err;
     unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);
     if (++e->epoch == 0) e->epoch = 1;
     if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s)) != hipSuccess) return err;
-    if (c->mixed && (err = compat_guard_invert(guard, s)) != hipSuccess) return err;       // (words 2, 3: the gathered rows' literal kernels, run_mixed)
     err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
     if (err != hipSuccess) return err;
     err = inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s, guard) : compat_forward_batch(d_a, n, d_tab, num, division, m, s, guard);

@@ -76,9 +76,6 @@ hipError_t compat_synth_splitmix(u64* d_a, unsigned n, unsigned num, unsigned di
 hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_flag, hipStream_t s);
 // the same as a stream-ordered check: guard[0] = epoch, and guard[1] = epoch when the tables differ
 hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s);
-// guard[2], guard[3] <- a pair that is EQUAL exactly when guard[0] != guard[1] (tables equal): literal kernels launched with guard + 2 run
-// only when the throughput kernels run too (the literal share of a mixed context inside a checked raw call, capi.cpp run_mixed)
-hipError_t compat_guard_invert(unsigned* d_guard, hipStream_t s);
 
 // ---- throughput kernels (kernels_fast.hip) ----
 // Device tables private to the fast path.  Built once per context from the reference-format tables.
@@ -93,15 +90,18 @@ struct FastTables {
     void* d_primes = nullptr;  // [P] PrimeDev records (ntt_core.cuh); the record BEFORE it holds the guard words {current epoch,
                                // epoch of the last table mismatch} of the checked raw calls (kGuardBit, capi.cpp)
     void* d_primes_alloc = nullptr;
-    int hl = 6;                // bits 0-3: headroom class = min over primes of (64 - bit length), capped at 6; bit 4: all primes near 2^k
+    int hl = 6;                // bits 0-3: headroom class = min over primes of (64 - bit length), capped at 6; bit 4: all primes near 2^k;
+                               // 0 (HL_LIT): the reference's literal arithmetic in the single-pass kernels
     const u64* d_psi = nullptr;     // reference-format tables owned by the context (fallback path)
     const u64* d_psiinv = nullptr;
 };
 
 // split_fwd (n = 2^16 contexts only, else null): per (virtual) prime the twiddle of the stage that couples the two halves
+// literal: kernel class HL_LIT (hl = 0) -- the transforms of this context return the reference's own words (singleBarrett with one
+// conditional subtraction carried through the stages, ntt_core.cuh), for contexts with a Barrett-inexact modulus
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
                               const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd = nullptr,
-                              const u64* split_inv = nullptr);
+                              const u64* split_inv = nullptr, bool literal = false);
 // n = 2^16 forward as two launches over half-size transforms, the coupling stage fused into the first (1.5 instead of 2 passes
 // over memory); _ok: the batch is large enough for the persistent kernels
 bool fast_forward_split16_ok(const FastTables& t, unsigned num);

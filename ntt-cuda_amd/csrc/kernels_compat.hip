@@ -351,18 +351,6 @@ hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsi
     return hipGetLastError();
 }
 
-static __global__ void guard_invert_kernel(unsigned* __restrict__ guard)
-{
-    const unsigned e = guard[0];
-    guard[2] = e;
-    guard[3] = guard[0] != guard[1] ? e : ~e;
-}
-hipError_t compat_guard_invert(unsigned* d_guard, hipStream_t s)
-{
-    guard_invert_kernel<<<1, 1, 0, s>>>(d_guard);
-    return hipGetLastError();
-}
-
 hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s)
 {
     tables_check_kernel<<<128, kBlock, 0, s>>>(d_x, d_y, n, count, d_guard, epoch);

@@ -224,7 +224,7 @@ unsigned* pair_flags(PairSlot* p) { return p->d_flags; }
 
 // ------------------------------------------------------------------------------------------------
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
-                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd, const u64* split_inv)
+                              const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd, const u64* split_inv, bool literal)
 {
     t->n = n;
     t->log_n = 0;
@@ -266,7 +266,7 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         d.delta = near_ok ? (u32)dl : 0;
         d.near_sh = pp.k > 32 ? pp.k - 32 : 0;
         d.near_mask = pp.k > 32 ? (u32)((1ull << (pp.k - 32)) - 1) : 0;
-        d.pad_ = 0;
+        d.lit = (literal && !pp.barrett_exact) ? 1u : 0u;
         d.twn[0] = TwPair{pp.ninv, shoup(pp.ninv, pp.q)};
         for (unsigned j = 1; j < 32; j++) {                   // (n >= 2048: the entries exist)
             const u64 w = mulmod(h_psiinv[(size_t)i * n + j], pp.ninv, pp.q);
@@ -275,6 +275,7 @@ hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, co
         if (!near_ok) all_near = false;
     }
     if (all_near) t->hl |= 16;
+    if (literal) t->hl = HL_LIT;                         // (the reference's own arithmetic: one class for every modulus size)
     if (split_fwd) {                                     // (n = 2^16 contexts: the device's pair flags exist before the first call)
         const hipError_t pe = pair_init_current_device();
         if (pe != hipSuccess) return pe;

@@ -11,59 +11,27 @@ namespace mi355ntt {
 
 // coalesced layout B0: register r of thread t holds coefficient (r << B0) | t; lane offset in a VGPR,
 // the r * (n/32) * 8 byte displacement in the buffer instruction's scalar offset
-// n = 2^11..2^14: layout 0 <-> memory through wave-local 16-byte row staging instead of a layout exchange + 8-byte accesses
-#ifndef MI355NTT_SMALL_ROW_STAGING
-#define MI355NTT_SMALL_ROW_STAGING 1
-#endif
 // PAIR16: issue order (0, 16, 1, 17, ...) -- the order in which a forward round on register bits 4..0 consumes the
 // registers (its first stage pairs r with r + 16; loads return in order, so the first butterfly can start after two loads
 // have landed instead of seventeen)
-#ifndef MI355NTT_FWD_LOAD_PAIR16
-#define MI355NTT_FWD_LOAD_PAIR16 1
-#endif
 template <int LOGN, bool PAIR16 = false>
 __device__ __forceinline__ void load_coalesced(u64 (&v)[32], const u64* __restrict__ poly, unsigned t)
 {
-#ifdef MI355NTT_ABLATE_GLOBAL
-#pragma unroll
-    for (int r = 0; r < 32; r++) v[r] = (u64)t * 0x9E3779B97F4A7C15ULL + r;
-    return;
-#endif
     const BufRsrc rs = make_rsrc(poly, Geo<LOGN>::N * 8u);
     static_for<32>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int r = PAIR16 ? ((i >> 1) | ((i & 1) << 4)) : i;
-#ifdef MI355NTT_ABLATE_LOADK     // timing experiments only (round 5, bound of pre-landing): the first K loads in issue order cost nothing
-        if constexpr (i < MI355NTT_ABLATE_LOADK) { v[r] = (u64)t * 0x9E3779B97F4A7C15ULL + r; return; }
-#endif
         v[r] = buf_load_u64(rs, t * 8u, ((unsigned)r << Geo<LOGN>::B0) * 8u);
         if constexpr (PAIR16) __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise re-sorts the loads by register)
     });
 }
 
-// cache policy of the coalesced 8-byte RESULT stores of k_inverse<LOGN> / k_polymul<LOGN> (n = 2^11 .. 2^14): 17 = written through,
-// as on n = 2^15 (MI355NTT_INV15_AUX_ST below).  A/B on one box, two rounds each: n = 2^13 inverse 0.171 -> 0.168 ms, n = 2^14 fused
-// 0.334 -> 0.329 ms per 256 MiB, every other size and kernel within +-0.5 %: small, never worse.
-#ifndef MI355NTT_INV_AUX_ST
-#define MI355NTT_INV_AUX_ST 17
-#endif
-template <int LOGN, int AUX = MI355NTT_STREAM_AUX_ST>
+// AUX: cache policy of the stores (the inverse / fused kernels' results are written through: Tune::kInvAuxSt, kInv15AuxSt)
+constexpr int kStoreCoalescedOps = 32;      // vector-memory instructions store_coalesced issues per lane (counted waits behind it rely on this)
+template <int LOGN, int AUX = Tune::kStreamAuxSt>
 __device__ __forceinline__ void store_coalesced(const u64 (&v)[32], u64* __restrict__ poly, unsigned t)
 {
-#ifdef MI355NTT_ABLATE_GLOBAL
-    u64 acc = 0;
-#pragma unroll
-    for (int r = 0; r < 32; r++) acc ^= v[r];
-    if (acc == 0x123456789ULL) poly[t] = acc;
-    return;
-#endif
-#ifdef MI355NTT_ABLATE_STORES     // timing experiments only: no result stores (results are wrong)
-    { u64 acc = 0;
-#pragma unroll
-      for (int r = 0; r < 32; r++) acc ^= v[r];
-      if (acc == 0x123456789ULL) poly[t] = acc;
-      return; }
-#endif
+    static_assert(kStoreCoalescedOps == 32, "one buffer_store_dwordx2 per register");
     const BufRsrc rs = make_rsrc(poly, Geo<LOGN>::N * 8u);
 #pragma unroll
     for (int r = 0; r < 32; r++) {
@@ -94,8 +62,7 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     auto tid = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
-    MI355NTT_STAMP(15);
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)y * G::N, tid());
+    load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)y * G::N, tid());
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -106,23 +73,13 @@ k_forward(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         u64* poly = a + (size_t)y * G::N;
-        MI355NTT_STAMP(0);
         forward_core<LOGN, HL, NEAR>(v, twp, tid, p, lds);
-        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
-        MI355NTT_STAMP(6);
-#if MI355NTT_SMALL_ROW_STAGING
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_forward<HL, NEAR>(v[decltype(rc)::value], p); });
         // layout 0 (32 consecutive words per thread) leaves through the wave's own 8 KiB of the image with 16-byte stores
         // (as on n = 2^15) instead of a workgroup-wide layout exchange and 8-byte stores
         __syncthreads();        // every wave has read the last exchange: the image is free
         wave_store_rows(v, lds + wave_s * 1024u, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
-        MI355NTT_STAMP(7);
-#else
-        exchange<LOGN, 0, G::B0>(v, lds, tid());
-        MI355NTT_STAMP(7);
-        store_coalesced<LOGN>(v, poly, tid());
-#endif
-        if (y + gridDim.x < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(y + gridDim.x) * G::N, tid());
-        MI355NTT_STAMP(8);
+        if (y + gridDim.x < num) load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)(y + gridDim.x) * G::N, tid());
         __syncthreads();        // the next polynomial's first exchange reuses the LDS image
     }
 }
@@ -141,15 +98,10 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
     auto tid = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
-    MI355NTT_STAMP(15);
-#if MI355NTT_SMALL_ROW_STAGING
     // rows (16-byte loads) through the wave's own 8 KiB of the image straight into layout 0: no layout exchange
     wave_load_rows(v, lds + wave_s * 1024u, make_rsrc(a + (size_t)y * G::N + wave_s * 2048u, 16384u), 0u, 0u);
     __syncthreads();        // every wave has left its staging slice: the first exchange writes the workgroup-wide image over them
                             // (later iterations are covered by the barrier at the loop's end)
-#else
-    load_coalesced<LOGN>(v, a + (size_t)y * G::N, tid());
-#endif
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -160,112 +112,24 @@ k_inverse(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         u64* poly = a + (size_t)y * G::N;
-        MI355NTT_STAMP(0);
-#if !MI355NTT_SMALL_ROW_STAGING
-        exchange<LOGN, G::B0, 0>(v, lds, tid());
-#endif
-        MI355NTT_STAMP(1);
         inverse_core<LOGN, HL, NEAR>(v, twp, tid, p, lds, primes[idx].twn);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
-        MI355NTT_STAMP(8);
-        store_coalesced<LOGN, MI355NTT_INV_AUX_ST>(v, poly, tid());
-#if MI355NTT_SMALL_ROW_STAGING
+        store_coalesced<LOGN, Tune::kInvAuxSt>(v, poly, tid());
         __syncthreads();        // every wave has read the last exchange: the image is free for the row staging
         if (y + gridDim.x < num)
             wave_load_rows(v, lds + wave_s * 1024u, make_rsrc(a + (size_t)(y + gridDim.x) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
-#else
-        if (y + gridDim.x < num) load_coalesced<LOGN>(v, a + (size_t)(y + gridDim.x) * G::N, tid());
-#endif
-        MI355NTT_STAMP(9);
         __syncthreads();
     }
 }
 
-// Wave priorities per phase (s_setprio; priority outranks age in the SIMD's issue arbitration).
-// Between two workgroup-wide exchanges the SIMD arbitrates strictly oldest-first, so its four waves run almost one
-// after the other and the last one finishes alone.  Lowering a wave's priority as it progresses past the exchange
-// (phase right after the exchange highest, the round that feeds the next exchange lowest) lets the waves that are
-// behind catch up: measured +3 % (1024 polynomials) to +7 % (8192) on k_forward15.
-#ifndef MI355NTT_PRIO_R1
-#define MI355NTT_PRIO_R1 0      // forward: R1 feeds the exchange
-#define MI355NTT_PRIO_R2 3      //          R2 follows it
-#define MI355NTT_PRIO_R3 2      //          R3: 2 for its first three stages, then 1 (MI355NTT_PSPLIT_R3 below): 6 processes
-#define MI355NTT_PSPLIT_R3 12   //          x 300 launches each, 0.1627-0.1646 ms per 1024 transforms against 0.165-0.176
-#define MI355NTT_PRIO_R3B 1     //          (profiles/r02_priority_and_noise.txt)
-#endif
-#ifndef MI355NTT_PRIO_I1
-#define MI355NTT_PRIO_I1 3      // inverse: R2' feeds the exchange (lowest); measured +3-4 % on k_inverse15
-#define MI355NTT_PRIO_I2 0
-#define MI355NTT_PRIO_I3 2
-#endif
-#define MI355NTT_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-// lab (round 5): priority by the wave's age on its SIMD (waves 4k .. 4k + 3 of a workgroup are the k-th oldest of their SIMDs) in the
-// round that feeds the workgroup-wide exchange: the SIMD arbitrates oldest first, so its four waves reach the barrier one after the
-// other; the youngest gets the highest priority there.  BASE + age, clamped to 3.
-__device__ __forceinline__ void setprio_by_age(unsigned wave_s, int base)
-{
-    const unsigned age = wave_s >> 2;
-    const int p = base + (int)age;
-    if (p <= 0) __builtin_amdgcn_s_setprio(0);
-    else if (p == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-}
-// optional second priority inside a round: from scheduling group PSPLIT on (-1 = none) the wave runs at priority ..B
-#ifndef MI355NTT_PSPLIT_R1
-#define MI355NTT_PSPLIT_R1 -1
-#define MI355NTT_PRIO_R1B 0
-#endif
-#ifndef MI355NTT_PSPLIT_R2
-#define MI355NTT_PSPLIT_R2 -1
-#define MI355NTT_PRIO_R2B 0
-#endif
-#ifndef MI355NTT_PSPLIT_R3
-#define MI355NTT_PSPLIT_R3 -1
-#define MI355NTT_PRIO_R3B 0
-#endif
-#ifndef MI355NTT_PSPLIT_I1
-#define MI355NTT_PSPLIT_I1 -1
-#define MI355NTT_PRIO_I1B 0
-#endif
-#ifndef MI355NTT_PSPLIT_I2
-#define MI355NTT_PSPLIT_I2 -1
-#define MI355NTT_PRIO_I2B 0
-#endif
-#ifndef MI355NTT_PSPLIT_I3
-#define MI355NTT_PSPLIT_I3 -1
-#define MI355NTT_PRIO_I3B 0
-#endif
-// Start-time stagger of the persistent workgroups: 8 phase groups, UNITS x 2048 cycles apart.  Every workgroup does the
-// same work, so without it all CUs load and store in the same instants and HBM sees bursts instead of a steady stream.
-// Measured on k_forward15 (tools/kbench.hip, warm): +7...10 % for 256...1024 polynomials with UNITS = 1 (at most
-// 6 us of delay), fading to +2 % at 2048 and nothing at 4096, where the workgroups drift apart by themselves; nothing
-// on k_inverse15 and -3 % on k_polymul15 at 256 polynomials, which are left alone.
-// Round 2 (inverse walking the batch downwards, profiles/r02_stagger_retune.txt): when a workgroup walks more than one
-// polynomial, 2 units on BOTH kernels give +2.5 % pairs at 512, +4 % at 768, +1.5...3 % at 1024, nothing from 2048 up; with one
-// polynomial per workgroup the delay is pure tail (-4 % at 2 units), so those launches keep 1 unit (forward) / none (inverse).
-#ifndef MI355NTT_STAGGER_FWD
-#define MI355NTT_STAGGER_FWD 1
-#endif
-#ifndef MI355NTT_STAGGER_INV
-#define MI355NTT_STAGGER_INV 0
-#endif
-#ifndef MI355NTT_STAGGER_FWD_MULTI
-#define MI355NTT_STAGGER_FWD_MULTI 2
-#endif
-#ifndef MI355NTT_STAGGER_INV_MULTI
-#define MI355NTT_STAGGER_INV_MULTI 2
-#endif
-#ifndef MI355NTT_STAGGER_MUL
-#define MI355NTT_STAGGER_MUL 0
-#endif
-// Round 5 (tools/probe/fused_small_ab.py, two processes each): the fused kernel with 2 units when a workgroup walks more than one polynomial --
-// 448 / 512 / 576 / 640 / 704 / 768 / 896 polynomials: -3.6 / -7.7 / -7.0 / -7.2 / -5.4 / -2.8 / -5.9 % per launch, 1024: +-0, 1280 ... 8192:
-// -0.5 ... -1.3 % (1 unit: about two thirds of that; 4 units: +4 % at 640 and 1024).  640 is the batched BFV encryption's launch (64
-// ciphertexts on 4 + 1 primes).
-#ifndef MI355NTT_STAGGER_MUL_MULTI
-#define MI355NTT_STAGGER_MUL_MULTI 2
-#endif
+// Wave priorities per phase (s_setprio; priority outranks age in the SIMD's issue arbitration; values: Tune::kPrio*, tune.hpp).
+// Between two workgroup-wide exchanges the SIMD arbitrates strictly oldest-first, so its four waves run almost one after the other
+// and the last one finishes alone.  Lowering a wave's priority as it progresses past the exchange (phase right after the exchange
+// highest, the round that feeds the next exchange lowest) lets the waves that are behind catch up: +3 % (1024 polynomials) to +7 %
+// (8192) on k_forward15.
+//
+// Start-time stagger of the persistent workgroups: 8 phase groups, UNITS x 2048 cycles apart (Tune::kStagger*).  Every workgroup
+// does the same work, so without it all CUs load and store in the same instants and HBM sees bursts instead of a steady stream.
 template <int UNITS, int UNITS_MULTI = UNITS>
 __device__ __forceinline__ void stagger_start(bool multi = false)
 {
@@ -275,57 +139,14 @@ __device__ __forceinline__ void stagger_start(bool multi = false)
         for (unsigned i = 0; i < n; i++) __builtin_amdgcn_s_sleep(32);
     }
 }
-// Cache policy of k_inverse15's (and k_polymul15's) coalesced 8-byte result stores (aux bits: 1 = sc0, 16 = sc1; 17 = written
-// through at system scope).  Written through, the L2s hold no dirty lines when the kernel ends: the write-back at the end of
-// the kernel -- part of the idle gap to the next launch -- disappears (round 2, launch log: 12.1 -> 8.7 us).  Measured again on
-// the frozen round-3 kernels (profiles/r03_structural_experiments.txt, batch C, three processes): inverse launches back to back
-// 0.1733 -> 0.1665 ms per 1024 transforms (-3.9 %), forward -> inverse pairs 0.3198 -> 0.3186 ms (-0.4 %, inside the noise but
-// never worse); sc1 alone gives the same, sc0 alone nothing.  Round 2 left it as a switch because the pairs did not move; it
-// ships since round 3 because a caller that runs inverse transforms on their own (decryption) gets the 4 %.
-#ifndef MI355NTT_INV15_AUX_ST
-#define MI355NTT_INV15_AUX_ST 17
-#endif
-// Cache policy of k_inverse15's 16-byte row loads in launches that stream (kStreamLoads in the division word: batches of 4096
-// polynomials = 1 GiB and more; aux bits: 2 = nt).  Round 5 (profiles/r05_streaming_overlap.txt, section 9; shipped library against a build
-// with the default policy, three processes each): non-temporal, inverse launches on their own run 1.8 / 2.4 / 2.3 / 0.8 % faster at 1024 /
-// 2048 / 4096 / 8192 polynomials -- a polynomial is read exactly once, and a line that does not displace the twiddle tables and the
-// result lines in the L2 is worth more than its own residency -- while forward -> inverse pairs, where the inverse reads what the forward
-// launch has just written, LOSE 0.5 / 0.8 / 0.3 % at 1024 / 2048 / 4096 and gain 0.1 % at 8192; sc0 / sc1 change nothing.  Pairs are
-// the common use and the contract's metric, so the hint is confined to the sizes where it costs them nothing measurable.  The forward
-// kernel's column loads lose 1.1 % with the same hint and keep the default, and so do the second operands of the fused product (shared
-// ones are re-read by every workgroup).  Only the load instructions exist twice in the code (wave_load_rows_half, alt).
-#ifndef MI355NTT_INV15_AUX_LD
-#define MI355NTT_INV15_AUX_LD 2
-#endif
-// k_polymul15's second operands arrive through LDS-direct loads (wave_load_rows_half_direct: no VGPRs and no ds_write pass on the way
-// into the slice; -0.6...-0.9 % at every batch size on its own) and, when every polynomial has its own (read exactly once; operands shared
-// by the batch or by a key group are re-read by every workgroup and keep the default policy) AND a and bhat together exceed the
-// memory-side cache (kStreamLoads: more than 512 polynomials), with the non-temporal hint: fused products -1.5 / -3.7 / -1.1 / -1.4 /
-// -1.1 % at 640 / 1024 / 2048 / 4096 / 8192 polynomials (round 5, tools/probe/invld_ab.py against the previous build, three processes
-// each); on batches the cache holds the hint costs 1-2 % (192 ... 512 polynomials, tools/probe/fused_small_ab.py: the next launch finds
-// less of them there).  The run-time choice is a branch around eight instructions that define no register; the 62-bit classes, whose
-// fused kernel sits at 128 VGPRs, answer even that with 596 bytes of scratch and keep the default policy.
-#ifndef MI355NTT_MUL15_B_AUX_LD
-#define MI355NTT_MUL15_B_AUX_LD 2
-#endif
+// k_inverse15's division word: kStreamLoads set for launches that stream (batches of kInvStreamLoadsMin polynomials = 1 GiB and more):
+// their 16-byte row loads carry the non-temporal hint (Tune::kInv15AuxLd).  Only the load instructions exist twice in the code
+// (wave_load_rows_half, alt).
 inline unsigned inv15_division_word(unsigned division, unsigned num) { return division | (num >= kInvStreamLoadsMin ? kStreamLoads : 0u); }
-// Order in which k_inverse15's persistent workgroups walk the batch: 1 = from the last polynomial down.  A forward
-// transform is normally followed by an inverse over the same polynomials (and the other way round): walking them in
-// opposite directions makes each kernel start on what the previous one wrote last, i.e. on what is still in the
-// memory-side cache, instead of on what a 256 MiB batch has already pushed out of it.
-#ifndef MI355NTT_INV_DESCENDING
-#define MI355NTT_INV_DESCENDING 1
-#endif
-// k_inverse15: the next polynomial's first column half pre-landed in the wave slices by LDS-direct loads issued behind the
-// workgroup-wide exchange (wave_preland_rows_half, ntt_core.cuh)
-#ifndef MI355NTT_INV_PRELAND
-#define MI355NTT_INV_PRELAND 1
-#endif
-#define MI355NTT_INV_POS(y) (MI355NTT_INV_DESCENDING ? num - 1u - (y) : (y))
-// timing experiments only (tools/kbench.hip): fold the polynomial index so the batch stays in the MALL or in L2
-#ifndef MI355NTT_POLY_SLOT
-#define MI355NTT_POLY_SLOT(y) (y)
-#endif
+// INV_POS(y): position of the y-th polynomial k_inverse15 walks: from the last polynomial down (Tune::kInvDescending).  A forward transform is
+// normally followed by an inverse over the same polynomials (and the other way round): walking them in opposite directions makes
+// each kernel start on what the previous one wrote last, i.e. on what is still in the memory-side cache.
+#define INV_POS(y) (Tune::kInvDescending ? num - 1u - (y) : (y))      // (`num`: the kernel's argument)
 
 // ================================================================================================
 // n = 2^15: one workgroup-wide exchange per transform, everything else wave-local (ntt_core.cuh).
@@ -382,20 +203,16 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     auto fresh_t = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
     unsigned y = blockIdx.x;
-    MI355NTT_WGSTAMP(0);
-    stagger_start<MI355NTT_STAGGER_FWD, MI355NTT_STAGGER_FWD_MULTI>(num > gridDim.x);
-    MI355NTT_WGSTAMP(1);
+    stagger_start<Tune::kStaggerFwd, Tune::kStaggerFwdMulti>(num > gridDim.x);
     // (SPLIT: half h of polynomial y is the half-size polynomial 2 y + h)
     [[maybe_unused]] unsigned h = 0;
     auto half_of = [](unsigned yy, unsigned hh) { return SPLIT ? 2 * yy + hh : yy; };
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(y, 0)) * G::N, fresh_t());
+    load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)(half_of(y, 0)) * G::N, fresh_t());
     if constexpr (SPLIT != 0) {
         const BufRsrc hrs = make_rsrc(a + (size_t)(half_of(y, 0) + 1) * G::N, G::N * 8u);
         split_partner_fetch<0>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
         split_partner_fetch<1>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
     }
-    [[maybe_unused]] int it = 0;
-    MI355NTT_STAMP_DECL
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -407,7 +224,7 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(half_of(y, h)) * G::N;
+        u64* poly = a + (size_t)(half_of(y, h)) * G::N;
         if constexpr (SPLIT != 0) if (h == 0) {
             // the stage that couples the halves, eight partner rows at a time (phases 0 and 1 were requested together with this
             // polynomial's own loads, at the tail of the previous iteration; phase c + 2 goes out as soon as phase c is read)
@@ -441,88 +258,31 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        MI355NTT_STAMPV(0, 0);
-#if defined(MI355NTT_STAMPS) && MI355NTT_STAMPS == 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // diagnostic build only: separates the load wait from round 1
-        MI355NTT_STAMPV(-1, 1);
-#endif
-#ifdef MI355NTT_PRIO_AGE_R1
-        setprio_by_age(wave_s, MI355NTT_PRIO_AGE_R1);
-#else
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
-#endif
-#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 1
-        // lab: the next polynomial's lines of this wave (32 chunks of 512 B, 8 KiB apart) touched by two vector loads a whole iteration
-        // ahead of their use (round 1 reads its twiddles through the scalar cache: nothing waits behind them in the queue)
-        u32 tch0 = 0, tch1 = 0;
-        if (SPLIT == 0 && ynext < num) {
-            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N + wave_s * 64u, 32u * 8192u);
-            const u32 ln = fresh_lane_id(), tvoff = (ln >> 2) * 8192u + (ln & 3u) * 128u;
-            tch0 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 0, 0);
-            tch1 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 16 * 8192, 0);
-        }
-#endif
-        ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, 0u, p);   // (round 1 reads no thread-derived value)
-#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 1
-        asm volatile("" ::"v"(tch0), "v"(tch1));
-#endif
-        MI355NTT_STAMPV(1, 2);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR1);
+        ct_round<LOGN, HL, 10, 4, NEAR, Tune::kPsplitR1, Tune::kPrioR1B>(v, twp, twr, 0u, p);   // (round 1 reads no thread-derived value)
         __syncthreads();                                  // every wave has left its private slice (previous polynomial)
-        MI355NTT_STAMPV(2, -1);
         exchange<LOGN, 10, 5>(v, lds, fresh_t());
-        MI355NTT_STAMPV(3, 3);
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
-        ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, fresh_t(), p);
-        MI355NTT_STAMPV(4, -1);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR2);
+        ct_round<LOGN, HL, 5, 4, NEAR, Tune::kPsplitR2, Tune::kPrioR2B>(v, twp, twr, fresh_t(), p);
         wave_transpose_5_to_0(v, lds + wave_s * WAVE_SLICE_WORDS, fresh_lane_id());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
-#if defined(MI355NTT_TOUCH_F) && (MI355NTT_TOUCH_F == 2 || MI355NTT_TOUCH_F == 3)
-        // lab: the same lines touched through the scalar cache at the start of the last round (~12 k cycles before the loads);
-        // MI355NTT_TOUCH_F == 3: the first sixteen chunks only
-        unsigned tsink = 0;
-        if (SPLIT == 0 && ynext < num)
-            touch_lines_scalar<(MI355NTT_TOUCH_F == 3 ? 16 : 32), 8192, 4, 128>(a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N + wave_s * 64u, tsink);
-#endif
-        ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
-#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 4
-        // lab: two vector loads behind the round's last twiddle load (nothing is issued behind them before the row stores)
-        u32 tch0 = 0, tch1 = 0;
-        if (SPLIT == 0 && ynext < num) {
-            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N + wave_s * 64u, 32u * 8192u);
-            const u32 ln = fresh_lane_id(), tvoff = (ln >> 2) * 8192u + (ln & 3u) * 128u;
-            tch0 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 0, 0);
-            tch1 = __builtin_amdgcn_raw_buffer_load_b32(nrs, tvoff, 16 * 8192, 0);
-        }
-#endif
-        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
-#if defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F == 4
-        asm volatile("" ::"v"(tch0), "v"(tch1));
-#elif defined(MI355NTT_TOUCH_F) && MI355NTT_TOUCH_F >= 2
-        touch_wait(tsink);
-#endif
-        MI355NTT_STAMPV(5, 4);
-#ifdef MI355NTT_PRIO_FMEM
-        MI355NTT_SETPRIO(MI355NTT_PRIO_FMEM);
-#endif
+        __builtin_amdgcn_s_setprio(Tune::kPrioR3);
+        ct_round<LOGN, HL, 0, 4, NEAR, Tune::kPsplitR3, Tune::kPrioR3B>(v, twp, twr, fresh_t(), p);
+        static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_forward<HL, NEAR>(v[decltype(rc)::value], p); });
         // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic instead of a VGPR kept live across the loop)
         wave_store_rows(v, lds + wave_s * WAVE_SLICE_WORDS, make_rsrc(poly + wave_s * 2048u, 16384u), 0u, 0u);
-        MI355NTT_STAMPV(-1, 5);
         if constexpr (SPLIT != 0) {
             if (h == 0) {
                 // next: the upper half of the same polynomial -- what this thread stored in the coupling stage above
-                load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly + G::N, fresh_t());
+                load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, poly + G::N, fresh_t());
             } else if (ynext < num) {
-                load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(half_of(ynext, 0)) * G::N, fresh_t());
+                load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)(half_of(ynext, 0)) * G::N, fresh_t());
                 const BufRsrc hrs = make_rsrc(a + (size_t)(half_of(ynext, 0) + 1) * G::N, G::N * 8u);
                 split_partner_fetch<0>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
                 split_partner_fetch<1>(hrs, lds + wave_s * WAVE_SLICE_WORDS, wave_s, fresh_lane_id());
             }
         } else {
-            if (ynext < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)MI355NTT_POLY_SLOT(ynext) * G::N, fresh_t());
+            if (ynext < num) load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)(ynext) * G::N, fresh_t());
         }
-        MI355NTT_STAMPV(6, 6);
-        if (it < 5) MI355NTT_WGSTAMP(2 + it);
-        it++;
         if (SPLIT != 0 && h == 0) {
             h = 1;                       // same polynomial, upper half
         } else {
@@ -531,8 +291,6 @@ k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
             ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep);
         }
     }
-    MI355NTT_STAMP_FLUSH
-    MI355NTT_WGSTAMP(7);
 }
 
 // n = 2^16 forward, cooperative: TWO workgroups per polynomial, one per output half (role 0 = lower, 1 = upper).  Both read the
@@ -595,12 +353,12 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
     // (no check of the dead mark here: an s_load ... glc + return in front of the first loads cost the kernel a third of its time --
     // 0.281 against 0.184 ms per 512 polynomials, measured -- and a workgroup of a dead launch notices in its poll loop anyway)
     {
-        const unsigned ph = (w >> 4) & 7u, units = ph * (num > npairs ? (unsigned)MI355NTT_STAGGER_FWD_MULTI : (unsigned)MI355NTT_STAGGER_FWD);
+        const unsigned ph = (w >> 4) & 7u, units = ph * (num > npairs ? (unsigned)Tune::kStaggerFwdMulti : (unsigned)Tune::kStaggerFwd);
         for (unsigned i = 0; i < units; i++) __builtin_amdgcn_s_sleep(32);
     }
     u64 v[32];
     auto request = [&](unsigned yy) {                     // everything of polynomial yy: U into registers, V (phases 0, 1) into the slice
-        load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(2 * yy) * G::N, fresh_t());
+        load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)(2 * yy) * G::N, fresh_t());
         const BufRsrc hrs = make_rsrc(a + (size_t)(2 * yy + 1u) * G::N, G::N * 8u);
         split_partner_fetch<0>(hrs, slice, wave_s, fresh_lane_id());
         split_partner_fetch<1>(hrs, slice, wave_s, fresh_lane_id());
@@ -641,16 +399,16 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
-        ct_round<LOGN, HL, 10, 4, NEAR, MI355NTT_PSPLIT_R1, MI355NTT_PRIO_R1B>(v, twp, twr, 0u, p);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR1);
+        ct_round<LOGN, HL, 10, 4, NEAR, Tune::kPsplitR1, Tune::kPrioR1B>(v, twp, twr, 0u, p);
         __syncthreads();                                  // every wave has left its private slice -- and holds its share of the input
         if (threadIdx.x == 0) __hip_atomic_store(flag_at(role), it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         exchange<LOGN, 10, 5>(v, lds, fresh_t());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
-        ct_round<LOGN, HL, 5, 4, NEAR, MI355NTT_PSPLIT_R2, MI355NTT_PRIO_R2B>(v, twp, twr, fresh_t(), p);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR2);
+        ct_round<LOGN, HL, 5, 4, NEAR, Tune::kPsplitR2, Tune::kPrioR2B>(v, twp, twr, fresh_t(), p);
         wave_transpose_5_to_0(v, slice, fresh_lane_id());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
-        ct_round<LOGN, HL, 0, 4, NEAR, MI355NTT_PSPLIT_R3, MI355NTT_PRIO_R3B>(v, twp, twr, fresh_t(), p);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR3);
+        ct_round<LOGN, HL, 0, 4, NEAR, Tune::kPsplitR3, Tune::kPrioR3B>(v, twp, twr, fresh_t(), p);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_2q(reduce_2q_sel<NEAR>(v[decltype(rc)::value], p), p.q); });
         wait_for_partner();                               // (a wave that gives up ends here: nothing is stored; ended waves leave the workgroup's barriers)
         asm volatile("" ::: "memory");                    // (compiler-level order: nothing of the row store moves above the poll)
@@ -688,18 +446,14 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
     u64 v[32];
     unsigned y = blockIdx.x;
     if (y >= num) return;
-    MI355NTT_WGSTAMP(0);
-    stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
-    MI355NTT_WGSTAMP(1);
+    stagger_start<Tune::kStaggerInv, Tune::kStaggerInvMulti>(num > gridDim.x);
     // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic)
-    wave_load_rows<MI355NTT_INV15_AUX_LD>(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
-    [[maybe_unused]] int it = 0;
-    MI355NTT_STAMP_DECL
+    wave_load_rows<Tune::kInv15AuxLd>(v, slice, make_rsrc(a + (size_t)INV_POS(y) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
-    unsigned ymod = __builtin_amdgcn_readfirstlane(MI355NTT_INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
-    if (MI355NTT_INV_DESCENDING && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    if (Tune::kInvDescending && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
     for (; y < num; y += gridDim.x, ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep)) {
         const unsigned ynext = y + gridDim.x;
@@ -707,81 +461,35 @@ k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* 
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(y)) * G::N;
-        MI355NTT_STAMP2(it, 0);
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
-        gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
-        MI355NTT_STAMP2(it, 1);
+        u64* poly = a + (size_t)INV_POS(y) * G::N;
+        __builtin_amdgcn_s_setprio(Tune::kPrioI1);
+        gs_round<LOGN, HL, 0, 0, NEAR, Tune::kPsplitI1, Tune::kPrioI1B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         wave_transpose_0_to_5(v, slice, fresh_lane_id());
-#ifdef MI355NTT_PRIO_AGE_I2
-        setprio_by_age(wave_s, MI355NTT_PRIO_AGE_I2);
-#else
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-#endif
-        gs_round<LOGN, HL, 5, 0, NEAR, MI355NTT_PSPLIT_I2, MI355NTT_PRIO_I2B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
-        MI355NTT_STAMP2(it, 2);
+        __builtin_amdgcn_s_setprio(Tune::kPrioI2);
+        gs_round<LOGN, HL, 5, 0, NEAR, Tune::kPsplitI2, Tune::kPrioI2B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         __syncthreads();                                  // private slices are idle from here on
-        MI355NTT_STAMP2(it, 3);
         exchange<LOGN, 5, 10>(v, lds, fresh_t());
-        MI355NTT_STAMP2(it, 4);
-#if MI355NTT_INV_PRELAND
         // (the exchange ends with a barrier: every slice is dead until this wave's own row staging) the next polynomial's first
         // column half starts its way from memory now and lands in the slice during the last round
         if (ynext < num)
-            wave_preland_rows_half<0, MI355NTT_INV15_AUX_LD>(slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), stream_loads);
-#endif
-#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
-        // lab: the second column half (the odd 128-byte lines of the wave's 16 KiB) touched through the scalar cache
-        unsigned tsink = 0;
-        if (ynext < num)
-            touch_lines_scalar<64, 256, 1, 128, 128>(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, tsink);
-#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
-        // lab: ... by one vector load behind the eight LDS-direct loads (older than the result stores: inside the counted wait below)
-        u32 tch = 0;
-        if (ynext < num) {
-            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u);
-            tch = __builtin_amdgcn_raw_buffer_load_b32(nrs, fresh_lane_id() * 256u + 128u, 0, 0);
-        }
-#endif
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
+            wave_preland_rows_half<0, Tune::kInv15AuxLd>(slice, make_rsrc(a + (size_t)INV_POS(ynext) * G::N + wave_s * 2048u, 16384u), stream_loads);
+        __builtin_amdgcn_s_setprio(Tune::kPrioI3);
+        gs_round<LOGN, HL, 10, 0, NEAR, Tune::kPsplitI3, Tune::kPrioI3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
-#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
-        touch_wait(tsink);
-#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
-        asm volatile("" ::"v"(tch));
-#endif
-        MI355NTT_STAMP2(it, 5);
-#ifdef MI355NTT_PRIO_IMEM
-        MI355NTT_SETPRIO(MI355NTT_PRIO_IMEM);
-#endif
-        store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
-#if MI355NTT_INV_PRELAND
+        store_coalesced<LOGN, Tune::kInv15AuxSt>(v, poly, fresh_t());
         if (ynext < num) {
-            // the eight LDS-direct loads are older than the 32 result stores: counted wait (hipcc does not order an LDS read behind
-            // the LDS-direct load that fills it; loads, stores and LDS-direct loads retire in issue order on one counter)
+            // the eight LDS-direct loads are older than the result stores of store_coalesced: counted wait for everything but those
+            // kStoreCoalescedOps stores (hipcc does not order an LDS read behind the LDS-direct load that fills it; on gfx950 loads,
+            // stores and LDS-direct loads of a wave retire in issue order on the one vmcnt counter -- probed, tools/probe/lds_direct.hip)
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStoreCoalescedOps) : "memory");
             u64 h[16];
             wave_read_prelanded_half(h, slice);
             static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
-#ifdef MI355NTT_INV15_HALF1_DIRECT      // lab: the second column half through LDS-direct loads as well
-            wave_load_rows_half_direct<1, MI355NTT_INV15_AUX_LD>(h, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), stream_loads);
-#else
-            wave_load_rows_half<1, MI355NTT_INV15_AUX_LD>(h, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
-#endif
+            wave_load_rows_half<1, Tune::kInv15AuxLd>(h, slice, make_rsrc(a + (size_t)INV_POS(ynext) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
             static_for<16>([&](auto rc) { v[16 + decltype(rc)::value] = h[decltype(rc)::value]; });
         }
-#else
-        if (ynext < num)
-            wave_load_rows<MI355NTT_INV15_AUX_LD>(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u, stream_loads);
-#endif
-        MI355NTT_STAMP2(it, 6);
-        if (it < 5) MI355NTT_WGSTAMP(2 + it);
-        it++;
     }
-    MI355NTT_STAMP_FLUSH
-    MI355NTT_WGSTAMP(7);
 }
 
 // n = 2^16 contexts (two half-size transforms per polynomial, see k_forward15 SPLIT; a kernel of its own so that k_inverse15's
@@ -809,21 +517,17 @@ k_inverse15_split(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPai
     u64 v[32];
     unsigned y = blockIdx.x;
     if (y >= num) return;
-    MI355NTT_WGSTAMP(0);
-    stagger_start<MI355NTT_STAGGER_INV, MI355NTT_STAGGER_INV_MULTI>(num > gridDim.x);
-    MI355NTT_WGSTAMP(1);
+    stagger_start<Tune::kStaggerInv, Tune::kStaggerInvMulti>(num > gridDim.x);
     // (SPLIT: half h of the polynomial at position pos is the half-size polynomial 2 pos + h)
     [[maybe_unused]] unsigned h = SPLIT ? 1u : 0u;
-    auto half_at = [&](unsigned yy, unsigned hh) { return SPLIT ? 2 * MI355NTT_INV_POS(yy) + hh : MI355NTT_INV_POS(yy); };
+    auto half_at = [&](unsigned yy, unsigned hh) { return SPLIT ? 2 * INV_POS(yy) + hh : INV_POS(yy); };
     // (the wave's 16 KiB chunk goes into the descriptor's base: scalar arithmetic)
-    wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(half_at(y, h)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
-    [[maybe_unused]] int it = 0;
-    MI355NTT_STAMP_DECL
+    wave_load_rows(v, slice, make_rsrc(a + (size_t)(half_at(y, h)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
-    unsigned ymod = __builtin_amdgcn_readfirstlane(MI355NTT_INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
-    if (MI355NTT_INV_DESCENDING && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
+    unsigned ymod = __builtin_amdgcn_readfirstlane(INV_POS(blockIdx.x) % division), ystep = __builtin_amdgcn_readfirstlane(gridDim.x % division);
+    if (Tune::kInvDescending && ystep) ystep = division - ystep;      // walking down: -grid = division - grid (mod division)
     asm volatile("" : "+s"(ymod), "+s"(ystep));          // in SGPRs from here on (the quotient sequence itself runs on the VALU)
     while (y < num) {
         const unsigned ynext = y + gridDim.x;
@@ -833,8 +537,7 @@ k_inverse15_split(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPai
         const PrimeDev p = primes[idx];
         const TwPair* twp = tw + (size_t)idx * G::N;
         const BufRsrc twr = make_rsrc(twp, G::N * 16u);
-        u64* poly = a + (size_t)MI355NTT_POLY_SLOT(half_at(y, h)) * G::N;
-        MI355NTT_STAMP2(it, 0);
+        u64* poly = a + (size_t)(half_at(y, h)) * G::N;
         if constexpr (MUL) {
             // pointwise product with the same half of bhat on the way in, streamed 16 words per lane at a time (as k_polymul15)
             const BufRsrc brs = make_rsrc(bhat + (size_t)half_at(y, h) * G::N + wave_s * 2048u, 16384u);
@@ -850,45 +553,22 @@ k_inverse15_split(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPai
                 v[16 + r] = FusedMul<HL, NEAR>::mul(v[16 + r], bb[r], p);
             });
         }
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I1);
-        gs_round<LOGN, HL, 0, 0, NEAR, MI355NTT_PSPLIT_I1, MI355NTT_PRIO_I1B, MUL && FusedMul<HL, NEAR>::LAZY>(v, twp, twr, fresh_t(), p, primes[idx].twn);
-        MI355NTT_STAMP2(it, 1);
+        __builtin_amdgcn_s_setprio(Tune::kPrioI1);
+        gs_round<LOGN, HL, 0, 0, NEAR, Tune::kPsplitI1, Tune::kPrioI1B, MUL && FusedMul<HL, NEAR>::LAZY>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         wave_transpose_0_to_5(v, slice, fresh_lane_id());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
-        gs_round<LOGN, HL, 5, 0, NEAR, MI355NTT_PSPLIT_I2, MI355NTT_PRIO_I2B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
-        MI355NTT_STAMP2(it, 2);
+        __builtin_amdgcn_s_setprio(Tune::kPrioI2);
+        gs_round<LOGN, HL, 5, 0, NEAR, Tune::kPsplitI2, Tune::kPrioI2B>(v, twp, twr, fresh_t(), p, primes[idx].twn);
         __syncthreads();                                  // private slices are idle from here on
-        MI355NTT_STAMP2(it, 3);
         exchange<LOGN, 5, 10>(v, lds, fresh_t());
-        MI355NTT_STAMP2(it, 4);
         if constexpr (SPLIT != 0) if (h == 0) {
             // (the exchange ends with a barrier: nobody reads or writes this wave's slice until the next iteration's row loads)
             const BufRsrc hrs = make_rsrc(poly + G::N, G::N * 8u);
             split_partner_fetch<0>(hrs, slice, wave_s, fresh_lane_id());
             split_partner_fetch<1>(hrs, slice, wave_s, fresh_lane_id());
         }
-#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
-        // lab: the second column half (the odd 128-byte lines of the wave's 16 KiB) touched through the scalar cache
-        unsigned tsink = 0;
-        if (ynext < num)
-            touch_lines_scalar<64, 256, 1, 128, 128>(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, tsink);
-#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
-        // lab: ... by one vector load behind the eight LDS-direct loads (older than the result stores: inside the counted wait below)
-        u32 tch = 0;
-        if (ynext < num) {
-            const BufRsrc nrs = make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u);
-            tch = __builtin_amdgcn_raw_buffer_load_b32(nrs, fresh_lane_id() * 256u + 128u, 0, 0);
-        }
-#endif
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
-        gs_round<LOGN, HL, 10, 0, NEAR, MI355NTT_PSPLIT_I3, MI355NTT_PRIO_I3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
+        __builtin_amdgcn_s_setprio(Tune::kPrioI3);
+        gs_round<LOGN, HL, 10, 0, NEAR, Tune::kPsplitI3, Tune::kPrioI3B>(v, twp, twr, 0u, p, primes[idx].twn);   // (the last round reads no thread-derived value)
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
-#if defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 1
-        touch_wait(tsink);
-#elif defined(MI355NTT_TOUCH_I) && MI355NTT_TOUCH_I == 2
-        asm volatile("" ::"v"(tch));
-#endif
-        MI355NTT_STAMP2(it, 5);
         if constexpr (SPLIT != 0) {
             if (h == 0) {
                 const BufRsrc lrs = make_rsrc(poly, G::N * 8u), hrs = make_rsrc(poly + G::N, G::N * 8u);
@@ -918,26 +598,23 @@ k_inverse15_split(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPai
                         const u64 hi = canon_2q(reduce_2q_sel<NEAR>(Tm, p), p.q);
                         v2u32 xl, xh;
                         xl.x = lo32(lo); xl.y = hi32(lo); xh.x = lo32(hi); xh.y = hi32(hi);
-                        __builtin_amdgcn_raw_buffer_store_b64(xl, lrs, voff, ((unsigned)r << G::B0) * 8u, MI355NTT_INV15_AUX_ST);
-                        __builtin_amdgcn_raw_buffer_store_b64(xh, hrs, voff, ((unsigned)r << G::B0) * 8u, MI355NTT_INV15_AUX_ST);
+                        __builtin_amdgcn_raw_buffer_store_b64(xl, lrs, voff, ((unsigned)r << G::B0) * 8u, Tune::kInv15AuxSt);
+                        __builtin_amdgcn_raw_buffer_store_b64(xh, hrs, voff, ((unsigned)r << G::B0) * 8u, Tune::kInv15AuxSt);
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 });
             } else {
-                store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
+                store_coalesced<LOGN, Tune::kInv15AuxSt>(v, poly, fresh_t());
             }
             // next: the lower half of the same polynomial, or the upper half of the next one (ONE load site: two of them meet at
             // the loop's back edge with different register assignments, and the fix-up spills)
-            const u64* nxt = h == 1 ? poly - G::N : a + (size_t)MI355NTT_POLY_SLOT(half_at(ynext, 1)) * G::N;
+            const u64* nxt = h == 1 ? poly - G::N : a + (size_t)(half_at(ynext, 1)) * G::N;
             if (h == 1 || ynext < num) wave_load_rows(v, slice, make_rsrc(nxt + wave_s * 2048u, 16384u), 0u, 0u);
         } else {
-            store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
+            store_coalesced<LOGN, Tune::kInv15AuxSt>(v, poly, fresh_t());
             if (ynext < num)
-                wave_load_rows(v, slice, make_rsrc(a + (size_t)MI355NTT_POLY_SLOT(MI355NTT_INV_POS(ynext)) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
+                wave_load_rows(v, slice, make_rsrc(a + (size_t)INV_POS(ynext) * G::N + wave_s * 2048u, 16384u), 0u, 0u);
         }
-        MI355NTT_STAMP2(it, 6);
-        if (it < 5) MI355NTT_WGSTAMP(2 + it);
-        it++;
         if (SPLIT != 0 && h == 1) {
             h = 0;                       // same polynomial, lower half
         } else {
@@ -946,8 +623,6 @@ k_inverse15_split(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPai
             ymod = (ymod + ystep >= division ? ymod + ystep - division : ymod + ystep);
         }
     }
-    MI355NTT_STAMP_FLUSH
-    MI355NTT_WGSTAMP(7);
 }
 
 // second-operand addressing of the fused products: one bhat polynomial per polynomial of a, or (kSharedB in the division
@@ -970,6 +645,7 @@ __host__ __device__ inline unsigned plain_division(unsigned division) { return (
 
 }  // namespace mi355ntt
 #include "kernels_lat.cuh"      // the small-batch kernels (need SharedB)
+#include "kernels_lit.cuh"      // kernel class HL_LIT: the reference's own arithmetic (contexts with a Barrett-inexact prime)
 namespace mi355ntt {
 
 template <int HL, bool NEAR>
@@ -991,8 +667,8 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
     u64* slice = lds + wave_s * WAVE_SLICE_WORDS;
     u64 v[32];
     unsigned y = blockIdx.x;
-    stagger_start<MI355NTT_STAGGER_MUL, MI355NTT_STAGGER_MUL_MULTI>(num > gridDim.x);
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)y * G::N, fresh_t());
+    stagger_start<Tune::kStaggerMul, Tune::kStaggerMulMulti>(num > gridDim.x);
+    load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)y * G::N, fresh_t());
     // modulus index of polynomial y, carried along in SGPRs instead of y % division per iteration (a division by a runtime
     // value is a multi-instruction VALU sequence; its reciprocal sat in a VGPR across the loop and was the forward kernel's
     // spill, reloaded behind a vmcnt(0) that also waited for the next polynomial's loads)
@@ -1008,24 +684,24 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         // (the wave's 16 KiB chunk of bhat goes into the descriptor's base)
         const BufRsrc brs = make_rsrc(bhat + (size_t)sb.index(y, idx, division) * G::N + wave_s * 2048u, 16384u);
         // ---- forward ----
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R1);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR1);
         ct_round<LOGN, HL, 10, 4, NEAR>(v, tf, tfr, 0u, p);   // (round 1 reads no thread-derived value)
         __syncthreads();
         exchange<LOGN, 10, 5>(v, lds, fresh_t());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R2);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR2);
         ct_round<LOGN, HL, 5, 4, NEAR>(v, tf, tfr, fresh_t(), p);
         wave_transpose_5_to_0(v, slice, fresh_lane_id());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_R3);
+        __builtin_amdgcn_s_setprio(Tune::kPrioR3);
         ct_round<LOGN, HL, 0, 4, NEAR>(v, tf, tfr, fresh_t(), p);
         // ---- pointwise product with bhat, streamed 16 words per lane at a time (layout 0 on both sides) ----
         {
             u64 bb[16];
-            wave_load_rows_half_direct<0, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && stream_b);
+            wave_load_rows_half_direct<0, Tune::kMul15BAuxLd>(bb, slice, brs, HL > 2 && stream_b);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[r] = FusedMul<HL, NEAR>::mul(v[r], bb[r], p);
             });
-            wave_load_rows_half_direct<1, MI355NTT_MUL15_B_AUX_LD>(bb, slice, brs, HL > 2 && stream_b);
+            wave_load_rows_half_direct<1, Tune::kMul15BAuxLd>(bb, slice, brs, HL > 2 && stream_b);
             static_for<16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 v[16 + r] = FusedMul<HL, NEAR>::mul(v[16 + r], bb[r], p);
@@ -1034,15 +710,15 @@ k_polymul15(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __r
         // ---- inverse ----
         gs_round<LOGN, HL, 0, 0, NEAR, -2, 0, FusedMul<HL, NEAR>::LAZY>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         wave_transpose_0_to_5(v, slice, fresh_lane_id());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I2);
+        __builtin_amdgcn_s_setprio(Tune::kPrioI2);
         gs_round<LOGN, HL, 5, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         __syncthreads();
         exchange<LOGN, 5, 10>(v, lds, fresh_t());
-        MI355NTT_SETPRIO(MI355NTT_PRIO_I3);
+        __builtin_amdgcn_s_setprio(Tune::kPrioI3);
         gs_round<LOGN, HL, 10, 0, NEAR>(v, ti, tir, fresh_t(), p, primes[idx].twn);
         static_for<32>([&](auto rc) { v[decltype(rc)::value] = canon_after_inverse<HL, NEAR>(v[decltype(rc)::value], p); });
-        store_coalesced<LOGN, MI355NTT_INV15_AUX_ST>(v, poly, fresh_t());
-        if (y + gridDim.x < num) load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, a + (size_t)(y + gridDim.x) * G::N, fresh_t());
+        store_coalesced<LOGN, Tune::kInv15AuxSt>(v, poly, fresh_t());
+        if (y + gridDim.x < num) load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, a + (size_t)(y + gridDim.x) * G::N, fresh_t());
     }
 }
 
@@ -1133,7 +809,7 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     asm volatile("" : "+s"(wave_s));
     auto tid = [&]() { return (wave_s << 6) | fresh_lane_id(); };
     u64 v[32];
-    load_coalesced<LOGN, MI355NTT_FWD_LOAD_PAIR16>(v, poly, tid());
+    load_coalesced<LOGN, Tune::kFwdLoadPair16>(v, poly, tid());
     forward_core<LOGN, HL, NEAR>(v, twf + (size_t)idx * G::N, tid, p, lds);
     // layout 0: this thread holds NTT values 32t .. 32t+31; the inverse starts from the same layout
     const BufRsrc brs = make_rsrc(bp, G::N * 8u);
@@ -1148,7 +824,7 @@ k_polymul(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __res
     inverse_core<LOGN, HL, NEAR, FusedMul<HL, NEAR>::LAZY>(v, twi + (size_t)idx * G::N, tid, p, lds, primes[idx].twn);
 #pragma unroll
     for (int r = 0; r < 32; r++) v[r] = canon_after_inverse<HL, NEAR>(v[r], p);
-    store_coalesced<LOGN, MI355NTT_INV_AUX_ST>(v, poly, tid());
+    store_coalesced<LOGN, Tune::kInvAuxSt>(v, poly, tid());
 }
 
 // Workgroups that can be resident at once: 256 CUs x (what 128 VGPRs/thread, the LDS image and 32 waves/CU admit).
@@ -1165,15 +841,30 @@ inline unsigned persistent_grid(unsigned num)
     return num < cap ? num : cap;
 }
 
+// class HL_LIT: a workgroup walks its polynomials in two passes by the kind of their prime (kernels_lit.cuh).  With a stride that
+// shares a factor with `division` a workgroup would meet only some of the primes -- all the literal work on a few workgroups -- so the
+// persistent grid shrinks until the two are coprime (division <= 16: a few steps).
+template <int LOGN>
+inline unsigned lit_grid(unsigned num, unsigned division)
+{
+    unsigned g = persistent_grid<LOGN>(num);
+    auto gcd = [](unsigned x, unsigned y) { while (y) { const unsigned t = x % y; x = y; y = t; } return x; };
+    while (g > 1 && g < num && gcd(g, division) != 1) g--;
+    return g;
+}
+
 template <int LOGN>
 hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                       hipStream_t s)
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
-#ifdef MI355NTT_ONLY_HL4N      // tools/kbench.hip: one instantiation only (compile time)
-    if constexpr (LOGN == 15) k_forward15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-#else
     using L = LatGeo<LOGN>;
+    if ((hl & 15) == HL_LIT) {      // the reference's own arithmetic (kernels_lit.cuh): single pass at every batch size
+        const dim3 gl(lit_grid<LOGN>(num, division));
+        if constexpr (LOGN == 15) k_forward15_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_forward_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        return hipGetLastError();
+    }
     if (use_latency_path<LOGN>(num, false)) {
         dispatch_class(hl, [&](auto hc, auto nc) {
             constexpr int H = decltype(hc)::value;
@@ -1189,7 +880,6 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
         if constexpr (LOGN == 15) k_forward15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_forward<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     });
-#endif
     return hipGetLastError();
 }
 
@@ -1198,10 +888,13 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
                       hipStream_t s)
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
-#ifdef MI355NTT_ONLY_HL4N
-    if constexpr (LOGN == 15) k_inverse15<4, true><<<g, b, 0, s>>>(d_a, tw, pr, inv15_division_word(division, num), base, num);
-#else
     using L = LatGeo<LOGN>;
+    if ((hl & 15) == HL_LIT) {
+        const dim3 gl(lit_grid<LOGN>(num, division));
+        if constexpr (LOGN == 15) k_inverse15_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_inverse_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        return hipGetLastError();
+    }
     if (use_latency_path<LOGN>(num, false)) {
         dispatch_class(hl, [&](auto hc, auto nc) {
             constexpr int H = decltype(hc)::value;
@@ -1217,7 +910,6 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
         if constexpr (LOGN == 15) k_inverse15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, inv15_division_word(division, num), base, num);
         else k_inverse<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     });
-#endif
     return hipGetLastError();
 }
 
@@ -1225,8 +917,14 @@ template <int LOGN>
 hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr, unsigned num,
                       unsigned division, hipStream_t s)
 {
-#ifndef MI355NTT_ONLY_HL4N
     using L = LatGeo<LOGN>;
+    if ((hl & 15) == HL_LIT) {
+        if constexpr (LOGN == 15)
+            k_polymul15_lit<LOGN><<<dim3(lit_grid<LOGN>(num, plain_division(division))), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
+        else
+            k_polymul_lit<LOGN><<<dim3(num), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division);
+        return hipGetLastError();
+    }
     if (use_latency_path<LOGN>(num, true)) {
         dispatch_class(hl, [&](auto hc, auto nc) {
             constexpr int H = decltype(hc)::value;
@@ -1247,19 +945,12 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
             k_polymul<LOGN, H, NR><<<dim3(num), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division);
         }
     });
-#endif
     return hipGetLastError();
 }
 
 
 // explicit per-size entry points (defined in kernels_fast_n<LOGN>.hip)
-#define MI355NTT_DECLARE_SIZE(LOGN)                                                                                          \
-    hipError_t fast_fwd_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,     \
-                               unsigned base, hipStream_t s);                                                                \
-    hipError_t fast_inv_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,     \
-                               unsigned base, hipStream_t s);                                                                \
-    hipError_t fast_mul_##LOGN(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr,  \
-                               unsigned num, unsigned division, hipStream_t s);
+#define MI355NTT_DECLARE_SIZE(LOGN)                                                                                               hipError_t fast_fwd_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,                                     unsigned base, hipStream_t s);                                                                     hipError_t fast_inv_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,                                     unsigned base, hipStream_t s);                                                                     hipError_t fast_mul_##LOGN(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr,                                  unsigned num, unsigned division, hipStream_t s);
 MI355NTT_DECLARE_SIZE(11)
 MI355NTT_DECLARE_SIZE(12)
 MI355NTT_DECLARE_SIZE(13)
@@ -1274,21 +965,6 @@ hipError_t fast_inv_split_16(int hl, u64* d_a, const u64* d_bhat, const TwPair* 
 hipError_t fast_fwd_split_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                              hipStream_t s);
 
-#define MI355NTT_DEFINE_SIZE(LOGN)                                                                                           \
-    hipError_t fast_fwd_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,     \
-                               unsigned base, hipStream_t s)                                                                 \
-    {                                                                                                                        \
-        return launch_fwd<LOGN>(hl, d_a, tw, pr, num, division, base, s);                                                    \
-    }                                                                                                                        \
-    hipError_t fast_inv_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,     \
-                               unsigned base, hipStream_t s)                                                                 \
-    {                                                                                                                        \
-        return launch_inv<LOGN>(hl, d_a, tw, pr, num, division, base, s);                                                    \
-    }                                                                                                                        \
-    hipError_t fast_mul_##LOGN(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr,  \
-                               unsigned num, unsigned division, hipStream_t s)                                               \
-    {                                                                                                                        \
-        return launch_mul<LOGN>(hl, d_a, d_b, twf, twi, pr, num, division, s);                                               \
-    }
+#define MI355NTT_DEFINE_SIZE(LOGN)                                                                                                hipError_t fast_fwd_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,                                     unsigned base, hipStream_t s)                                                                      {                                                                                                                                 return launch_fwd<LOGN>(hl, d_a, tw, pr, num, division, base, s);                                                         }                                                                                                                             hipError_t fast_inv_##LOGN(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division,                                     unsigned base, hipStream_t s)                                                                      {                                                                                                                                 return launch_inv<LOGN>(hl, d_a, tw, pr, num, division, base, s);                                                         }                                                                                                                             hipError_t fast_mul_##LOGN(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr,                                  unsigned num, unsigned division, hipStream_t s)                                                    {                                                                                                                                 return launch_mul<LOGN>(hl, d_a, d_b, twf, twi, pr, num, division, s);                                                    }
 
 }  // namespace mi355ntt

@@ -17,25 +17,7 @@
 #include <utility>
 
 #include "modarith.cuh"
-
-// ---- the lab is not the product ---------------------------------------------------------------------------------------
-// The kernels carry compile-time switches for measurement builds (tools/kbench.hip via tools/build_kbench.sh): ablations
-// that produce WRONG RESULTS (MI355NTT_ABLATE_*), in-kernel time stamps, tuning knobs (priorities, stagger, cache policy,
-// ring shapes, ...).  They are honoured only together with -DMI355NTT_LAB, which no library build sets: a stray -D in
-// CXXFLAGS then stops the compilation instead of shipping a different kernel.
-#ifndef MI355NTT_LAB
-#if defined(MI355NTT_ABLATE_EXCHANGE) || defined(MI355NTT_ABLATE_TWIDDLE) || defined(MI355NTT_ABLATE_GLOBAL) || defined(MI355NTT_ABLATE_TWL1) || defined(MI355NTT_ABLATE_COMPUTE) || defined(MI355NTT_ABLATE_ROWS) || defined(MI355NTT_ABLATE_LOADK) || defined(MI355NTT_ABLATE_STORES) || defined(MI355NTT_INV_PRELAND) || defined(MI355NTT_PRIO_IMEM) || defined(MI355NTT_PRIO_FMEM) || defined(MI355NTT_PRIO_AGE_R1) || defined(MI355NTT_PRIO_AGE_I2) || defined(MI355NTT_TOUCH_F) || defined(MI355NTT_TOUCH_I) || defined(MI355NTT_ROWS_AUX_LD) || defined(MI355NTT_INV15_AUX_LD) || defined(MI355NTT_MUL15_B_AUX_LD) || defined(MI355NTT_INV15_HALF1_DIRECT) || defined(MI355NTT_STAGGER_MUL_MULTI) || \
-    defined(MI355NTT_STAMPS) || defined(MI355NTT_POLY_SLOT) || defined(MI355NTT_ONLY_HL4N) || defined(MI355NTT_STREAM_AUX_LD) || \
-    defined(MI355NTT_STREAM_AUX_ST) || defined(MI355NTT_TWO_PHASE_MIN_LOGN) || defined(MI355NTT_INV_MERGED_LOADS) || \
-    defined(MI355NTT_SCHED_GROUP) || defined(MI355NTT_RING_GROUP_B0) || defined(MI355NTT_RING_DEPTH_B0) || defined(MI355NTT_MAD_CHAIN) || \
-    defined(MI355NTT_SMALL_ROW_STAGING) || defined(MI355NTT_FWD_LOAD_PAIR16) || defined(MI355NTT_PRIO_R1) || defined(MI355NTT_PRIO_I1) || \
-    defined(MI355NTT_PSPLIT_R1) || defined(MI355NTT_PSPLIT_R2) || defined(MI355NTT_PSPLIT_R3) || defined(MI355NTT_PSPLIT_I1) || \
-    defined(MI355NTT_PSPLIT_I2) || defined(MI355NTT_PSPLIT_I3) || defined(MI355NTT_STAGGER_FWD) || defined(MI355NTT_STAGGER_INV) || \
-    defined(MI355NTT_STAGGER_FWD_MULTI) || defined(MI355NTT_STAGGER_INV_MULTI) || defined(MI355NTT_STAGGER_MUL) || \
-    defined(MI355NTT_INV15_AUX_ST) || defined(MI355NTT_INV_AUX_ST) || defined(MI355NTT_INV_DESCENDING) || defined(MI355NTT_CANON_SIGN) || defined(MI355NTT_NEAR60_N1_SHIFT)
-#error "MI355NTT_* experiment switches are for measurement builds only: add -DMI355NTT_LAB (tools/build_kbench.sh); a library build must not define them"
-#endif
-#endif
+#include "tune.hpp"      // the tuning constants of these kernels: ONE struct (measurement builds substitute their own, tools/build_kbench.sh)
 
 namespace mi355ntt {
 
@@ -51,62 +33,6 @@ __device__ __forceinline__ void static_for(F&& f)
 {
     static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
-
-// Optional in-kernel phase stamps (diagnostic builds only: -DMI355NTT_STAMPS, tools/kbench.hip).  Stamp values
-// go to a buffer of their own and never feed an output.
-#ifdef MI355NTT_STAMPS
-__device__ unsigned long long* g_stamp_buf;
-// Segment timing with scalar accumulators only (no VGPRs, no memory traffic inside the loop): each wave adds the
-// shader-clock time between consecutive marks into 8 SGPR sums and stores them once after the loop.
-struct StampAcc {
-    unsigned long long prev, sum[8];
-};
-__device__ __forceinline__ unsigned long long stamp_now()
-{
-    unsigned long long tm;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
-    return tm;
-}
-__device__ __forceinline__ unsigned long long stamp_real()
-{
-    unsigned long long tm;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
-    return tm;
-}
-#define MI355NTT_STAMP_DECL StampAcc sacc; sacc.prev = stamp_now(); for (int k_ = 0; k_ < 8; k_++) sacc.sum[k_] = 0; unsigned long long real0_ = stamp_real(), clk0_ = sacc.prev;
-// MI355NTT_STAMPS == 2: a second slot assignment of the forward kernel that resolves the end of the iteration (wait for the
-// loaded polynomial / round 1 / exchange / rounds 2+3 / row store / next loads): MI355NTT_STAMPV(slot in layout 1, in layout 2), -1 = no mark
-#define MI355NTT_STAMPV(s1, s2) { if ((MI355NTT_STAMPS == 2 ? (s2) : (s1)) >= 0) MI355NTT_STAMP2(0, (MI355NTT_STAMPS == 2 ? (s2) : (s1))) }
-#define MI355NTT_STAMP2(it, slot) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = stamp_now(); sacc.sum[slot] += n_ - sacc.prev; sacc.prev = n_; __builtin_amdgcn_sched_barrier(0); }
-#define MI355NTT_STAMP_FLUSH { unsigned long long real1_ = stamp_real(), clk1_ = stamp_now(); sacc.sum[7] = ((clk1_ - clk0_) << 24) / (real1_ - real0_ + 1); /* shader cycles per 100 MHz tick, x 2^24 */ \
-    if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 8; k_++) g_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k_] = sacc.sum[k_]; } }
-// workgroup timeline in s_memrealtime ticks (100 MHz): slot 0 kernel entry, 1 after the start stagger, 2 + i end of
-// iteration i (i < 5), 7 exit; written by thread 0 only
-__device__ unsigned long long* g_wg_buf;
-// launch log: every workgroup appends its entry and exit time (all launches since the log was reset), so that the idle
-// gap between back-to-back launches -- last exit of one to first entry of the next -- can be read off
-__device__ unsigned long long* g_wg_log;          // [0]: entries logged, [1]: exits logged, [2 + i] entry i, [2 + cap + i] exit i
-constexpr unsigned kWgLogCap = 1u << 16;
-#define MI355NTT_WGSTAMP(slot)                                                                                             \
-    {                                                                                                                      \
-        if (threadIdx.x == 0) {                                                                                            \
-            const unsigned long long now_ = stamp_real();                                                                  \
-            g_wg_buf[(size_t)blockIdx.x * 8 + (slot)] = now_;                                                              \
-            if ((slot) == 0 || (slot) == 7) {                                                                              \
-                const unsigned long long k_ = atomicAdd(g_wg_log + ((slot) == 7), 1ull);                                   \
-                if (k_ < kWgLogCap) g_wg_log[2 + ((slot) == 7 ? kWgLogCap : 0u) + k_] = now_;                              \
-            }                                                                                                              \
-        }                                                                                                                  \
-    }
-#define MI355NTT_STAMP(slot)
-#else
-#define MI355NTT_STAMPV(s1, s2)
-#define MI355NTT_WGSTAMP(slot)
-#define MI355NTT_STAMP(slot)
-#define MI355NTT_STAMP2(it, slot)
-#define MI355NTT_STAMP_DECL
-#define MI355NTT_STAMP_FLUSH
-#endif
 
 struct TwPair {       // {w, floor(w * 2^64 / q)}
     u64 w, wp;
@@ -127,7 +53,8 @@ struct PrimeDev {
     u32 delta;        // 2^k - q when that is small ("near-2^k" prime, the shape of every SEAL-style modulus), else 0
     u32 near_sh;      // k - 32
     u32 near_mask;    // 2^(k-32) - 1
-    u32 pad_;
+    u32 lit;          // contexts of kernel class HL_LIT only: 1 = this prime is Barrett-inexact -- its polynomials take the literal
+                      // butterflies; 0 = the reference's words are the exact transform's, its polynomials take the lazy ones (else 0)
     // n^-1 folded into the LAST inverse round (gs_round, SCALE): twn[0] = {n^-1, companion}, twn[i] = psi^-bitrev(i) * n^-1
     // for i = 1..31 -- the twiddles of the top five GS stages (reference table entries [1, 32)) times n^-1.
     TwPair twn[32];
@@ -171,24 +98,10 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, u32 bytes)
     const u32 lo = __builtin_amdgcn_readfirstlane(lo32(b)), hi = __builtin_amdgcn_readfirstlane(hi32(b));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((u64)hi << 32) | lo), 0, bytes, 0x00020000);
 }
-// Cache policy of the polynomial stream (aux bits of the buffer instructions: 2 = nt).  Measured (tools/memsys_experiments.sh):
-// nt loads are within noise on the forward kernel and cost the inverse 4-5 % at 4096 polynomials, nt stores cost 3-7 %
-// everywhere -- the default policy stays.
-#ifndef MI355NTT_STREAM_AUX_LD
-#define MI355NTT_STREAM_AUX_LD 0
-#endif
-#ifndef MI355NTT_STREAM_AUX_ST
-#define MI355NTT_STREAM_AUX_ST 0
-#endif
-// ... of the 16-byte row loads alone (the inverse and fused kernels' polynomial loads, wave_load_rows* / wave_preland_rows_half): lab switch
-// of round 5 -- non-temporal row loads speed up inverse launches on their own by 3-4 % at 8192 polynomials and leave forward -> inverse
-// pairs where they were (profiles/r05_streaming_overlap.txt, section 7)
-#ifndef MI355NTT_ROWS_AUX_LD
-#define MI355NTT_ROWS_AUX_LD MI355NTT_STREAM_AUX_LD
-#endif
+// (cache policy of the polynomial stream: Tune::kStreamAuxLd / kStreamAuxSt, tune.hpp)
 __device__ __forceinline__ u64 buf_load_u64(BufRsrc r, u32 voff, u32 soff)
 {
-    const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, MI355NTT_STREAM_AUX_LD);
+    const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, Tune::kStreamAuxLd);
     return (u64)x.x | ((u64)x.y << 32);
 }
 __device__ __forceinline__ void buf_store_u64(BufRsrc r, u32 voff, u32 soff, u64 v)
@@ -196,7 +109,7 @@ __device__ __forceinline__ void buf_store_u64(BufRsrc r, u32 voff, u32 soff, u64
     v2u32 x;
     x.x = lo32(v);
     x.y = hi32(v);
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, MI355NTT_STREAM_AUX_ST);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, Tune::kStreamAuxSt);
 }
 __device__ __forceinline__ TwPair buf_load_tw(BufRsrc r, u32 voff, u32 soff)
 {
@@ -212,19 +125,9 @@ __device__ __forceinline__ TwPair buf_load_tw(BufRsrc r, u32 voff, u32 soff)
 // ------------------------------------------------------------------------------------------------
 
 // y*w mod q, result congruent and in [0, 4q).  y: any 64-bit value.  wp = floor(w*2^64/q).
-// Quotient estimate from three of the four partial products (error <= 2), remainder as y*w + h*(2^64-q).
+// Quotient estimate h from three of the four partial products (error <= 2), remainder as y*w + h*(2^64-q): mul_shoup4m below.
 //
-// (gfx950 issues 32-bit multiplies, 64-bit adds and 3-operand adds at half rate; v_mad_u64_u32 costs about 1.6x a
-// v_mul_lo_u32, so variants that chain four of them on the high word -- 6 instead of 8 instructions for the
-// remainder -- measured slower: tools/ubench_bfly.hip variants 5 and 9.)
-__device__ __forceinline__ u64 mul_shoup4(u64 y, u64 w, u64 wp, u64 nq)
-{
-    u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
-    u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
-    return y * w + h * nq;
-}
-
-// The same product with the four cross terms y0*w1 + y1*w0 + h0*n1 + h1*n0 (only their low 32 bits matter) accumulated
+// The four cross terms y0*w1 + y1*w0 + h0*n1 + h1*n0 of that remainder (only their low 32 bits matter) are accumulated
 // by a chain of v_mad_u64_u32 instead of four v_mul_lo_u32 + two v_add3_u32.  Measured on gfx950 with every wave busy
 // until a common deadline (tools/ubench_issue.hip, profiles/r02_ubench_issue_costs.txt): v_mad_u64_u32 issues in 4.1
 // cycles per wave-instruction, the same as v_mul_lo_u32 / v_mul_hi_u32 / v_add3_u32 / v_lshl_add_u64 (4.0 ... 4.3; only
@@ -256,22 +159,10 @@ __device__ __forceinline__ u64 shoup_rem_chain(u64 y, u64 w, u64 h, u64 nq, u64 
     const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w), n0 = lo32(nq), n1 = hi32(nq);
     const u32 h0 = lo32(h), h1 = hi32(h);
     const u64 acc = mad32(h0, n0, mad32(y0, w0, base));
-#ifdef MI355NTT_NEAR60_N1_SHIFT
-    // lab switch (round 4, energy experiment; 60-bit near-2^k primes only: the high word of 2^64 - q is 0xF0000000): h0 * n1 mod 2^32 is
-    // -(h0 << 28) -- a shift and a subtract (cheap instructions, profiles/r04_power_cap_and_overlap.txt batch E) instead of one multiply-add
-    (void)n1;
-    const u64 c = mad32_chain<true>(h1, n0, mad32_chain<TWS>(y1, w0, mad32_chain0<TWS>(y0, w1)));
-    u32 xh = hi32(acc), sh;
-    asm("v_lshlrev_b32 %0, 28, %1" : "=v"(sh) : "v"(h0));
-    asm("v_add_u32 %0, %0, %1" : "+v"(xh) : "v"(lo32(c)));
-    asm("v_sub_u32 %0, %0, %1" : "+v"(xh) : "v"(sh));
-    return ((u64)xh << 32) | lo32(acc);
-#else
     const u64 c = mad32_chain<true>(h1, n0, mad32_chain<true>(h0, n1, mad32_chain<TWS>(y1, w0, mad32_chain0<TWS>(y0, w1))));
     u32 xh = hi32(acc);
     asm("v_add_u32 %0, %0, %1" : "+v"(xh) : "v"(lo32(c)));     // (as C++ the compiler re-associates it into a 64-bit add of {0, c})
     return ((u64)xh << 32) | lo32(acc);
-#endif
 }
 // y*w + h*(2^64 - q) + base  (mod 2^64); without base: congruent to y*w and in [0, 4q).  nq is always scalar (PrimeDev).
 template <bool TWS>
@@ -295,29 +186,7 @@ template <bool EXACT>
 __device__ __forceinline__ u64 mul_shoup(u64 y, u64 w, u64 wp, u64 nq)
 {
     if constexpr (EXACT) return mul_shoup2(y, w, wp, nq);
-    else return mul_shoup4(y, w, wp, nq);
-}
-
-// CT butterfly (a, b) <- (a + T, a + cq - T) with T = b*w mod q in [0, 4q) as in mul_shoup4, fused: `a` rides in the
-// 64-bit addend of the lo*lo multiply-adds, so a + T costs no add of its own, and the difference is formed as
-// (2a + cq) - (a + T) with one shift-add: 15 VALU instructions instead of 16 (+7.5 % in tools/ubench_bfly.hip, variant
-// 11 vs 1).  It keeps one more 64-bit value live per butterfly; measured on k_forward15: +3 % with the 7-instruction
-// partial reduction (general primes), -2 % with the 3-instruction one (NEAR), so ct_round uses it for the former only.
-// The two empty asm statements pin values the compiler would otherwise re-associate back.
-__device__ __forceinline__ void ct_bfly4(u64& a, u64& b, u64 w, u64 wp, u64 nq, u64 cq)
-{
-    const u64 U = a, y = b;
-    u64 D = (U << 1) + cq;
-    asm("" : "+v"(D));
-    const u32 y0 = lo32(y), y1 = hi32(y), p0 = lo32(wp), p1 = hi32(wp);
-    const u32 w0 = lo32(w), w1 = hi32(w), n0 = lo32(nq), n1 = hi32(nq);
-    const u64 h = mad32(y1, p1, (u64)__umulhi(y0, p1)) + (u64)__umulhi(y1, p0);
-    const u32 h0 = lo32(h), h1 = hi32(h);
-    const u64 acc = mad32(h0, n0, mad32(y0, w0, U));
-    u32 xh = hi32(acc) + y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
-    asm("" : "+v"(xh));
-    a = ((u64)xh << 32) | lo32(acc);
-    b = D - a;
+    else return mul_shoup4m<false>(y, w, wp, nq);
 }
 
 // x in [0, B*q) (B*q < 2^64, B <= 66 or B*q < 2^(k+5)) -> congruent value in [0, 2q).
@@ -367,22 +236,9 @@ __device__ __forceinline__ u64 mul_fold_near(u64 x, u64 b, const PrimeDev& p)
 }
 
 // [0, 2q) -> [0, q)
-// MI355NTT_CANON_SIGN (lab switch, round 4): x - q as ONE 64-bit add of 2^64 - q (v_lshl_add_u64) and the select on its sign -- x < 2q <
-// 2^63, so x - q is negative exactly when x < q -- instead of a 64-bit compare, a subtract pair and the select.
-#ifndef MI355NTT_CANON_SIGN
-#define MI355NTT_CANON_SIGN 0
-#endif
 __device__ __forceinline__ u64 canon_2q(u64 x, u64 q)
 {
-#if MI355NTT_CANON_SIGN
-    u64 t;
-    const u64 nq = 0ULL - q;
-    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(t) : "v"(x), "s"(nq));      // (as C++ the compiler goes back to compare + subtract pair)
-    const int th = (int)hi32(t);
-    return th < 0 ? x : t;
-#else
     return x >= q ? x - q : x;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -443,10 +299,7 @@ struct Geo {
     static constexpr int T = N / 32;                  // threads per polynomial
     static constexpr int B0 = LOGN - 5;               // coalesced layout: i = (r << B0) | t
     static constexpr int NR = (LOGN + 4) / 5;         // rounds
-#ifndef MI355NTT_TWO_PHASE_MIN_LOGN
-#define MI355NTT_TWO_PHASE_MIN_LOGN 13   // half-size image from n = 2^13 up: 2-4 workgroups share a CU (n = 2^15 needs it to fit at all)
-#endif
-    static constexpr bool TWO_PHASE = (LOGN >= MI355NTT_TWO_PHASE_MIN_LOGN);   // LDS image holds half a polynomial at a time
+    static constexpr bool TWO_PHASE = (LOGN >= Tune::kTwoPhaseMinLogN);   // LDS image holds half a polynomial at a time
     static constexpr int PB = LOGN - 1;               // index bit that selects the phase
     static constexpr int ROWS = (TWO_PHASE ? N / 2 : N) / 32;
     static constexpr int LDS_WORDS = (LOGN == 15) ? 16 * 1152 : ROWS * 34;   // image (32 + 2 pad words per row); n = 2^15: 16 wave slices of 9216 B
@@ -501,9 +354,6 @@ __device__ __forceinline__ void lds_write2_u64(u64* addr, u64 a, u64 b)
 template <int LOGN, int BO, int BN>
 __device__ __forceinline__ void exchange(u64 (&v)[32], u64* lds, unsigned t)
 {
-#ifdef MI355NTT_ABLATE_EXCHANGE      // timing experiments only (tools/kbench.hip): results are wrong
-    return;
-#endif
     __builtin_amdgcn_sched_barrier(0);   // keep the next round's twiddle loads (and anything else) out of the exchange
     using G = Geo<LOGN>;
     constexpr int PH = G::TWO_PHASE ? 2 : 1;
@@ -658,15 +508,6 @@ __device__ __forceinline__ unsigned fresh_lane_id()
 
 __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, BufRsrc dst, unsigned wave_byte_off, unsigned)
 {
-#ifdef MI355NTT_ABLATE_ROWS          // timing experiments only: no row stores (results are wrong)
-    u64 acc = 0;
-    static_for<32>([&](auto rc) { acc ^= v[decltype(rc)::value]; });
-    if (acc == 0x123456789ULL) slice[0] = acc;
-    return;
-#endif
-#ifdef MI355NTT_ABLATE_STORES        // timing experiments only: the LDS staging stays, the global stores go
-#define MI355NTT_ROWSTORE_SKIP 1
-#endif
     __builtin_amdgcn_sched_barrier(0);
     const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
@@ -684,10 +525,7 @@ __device__ __forceinline__ void wave_store_rows(const u64 (&v)[32], u64* slice, 
             const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz_store(8 * k + rr)) << 4));
             v4u32 x;
             x.x = lo32(pr.x); x.y = hi32(pr.x); x.z = lo32(pr.y); x.w = hi32(pr.y);
-#ifdef MI355NTT_ROWSTORE_SKIP
-            if (x.x == 0x12345u && x.w == 0x54321u)
-#endif
-            __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, MI355NTT_STREAM_AUX_ST);
+            __builtin_amdgcn_raw_buffer_store_b128(x, dst, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, Tune::kStreamAuxSt);
         });
         wave_lds_fence();
     });
@@ -698,24 +536,21 @@ __device__ __forceinline__ void issue_row_loads(v4u32 (&x)[8], BufRsrc src, unsi
 {
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-#ifdef MI355NTT_ABLATE_LOADK     // timing experiments only (round 5, bound of pre-landing): the first K/2 of the 16 row loads cost nothing
-        if constexpr (8 * CH + k < MI355NTT_ABLATE_LOADK / 2) { x[k] = v4u32{voff, voff, voff, voff}; return; }
-#endif
         x[k] = __builtin_amdgcn_raw_buffer_load_b128(src, voff, k * 2048u + CH * 128u, AUX);
     });
 }
 // one column half (CH = 0/1): 16 words of this lane's row into out[0..15].  AUX_ALT: cache-policy bits of the global loads when the
 // (wave-uniform) run-time flag `alt` is set -- only the eight load instructions are issued twice in the code, the rest is shared
-template <int CH, int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+template <int CH, int AUX_ALT = Tune::kRowsAuxLd>
 __device__ __forceinline__ void wave_load_rows_half(u64 (&out)[16], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned, bool alt = false)
 {
     const unsigned lane = fresh_lane_id();
     char* base = reinterpret_cast<char*>(slice);
     const unsigned sw = lane & 7, rr = lane >> 3;
     v4u32 x[8];
-    if (AUX_ALT != MI355NTT_ROWS_AUX_LD && alt) issue_row_loads<CH, AUX_ALT>(x, src, wave_byte_off + rr * 256u + sw * 16u);
-    else issue_row_loads<CH, MI355NTT_ROWS_AUX_LD>(x, src, wave_byte_off + rr * 256u + sw * 16u);
-    if constexpr (AUX_ALT != MI355NTT_ROWS_AUX_LD) __builtin_amdgcn_sched_barrier(0);     // (a convergent join: keeps the compiler from duplicating the staging code below into both arms)
+    if (AUX_ALT != Tune::kRowsAuxLd && alt) issue_row_loads<CH, AUX_ALT>(x, src, wave_byte_off + rr * 256u + sw * 16u);
+    else issue_row_loads<CH, Tune::kRowsAuxLd>(x, src, wave_byte_off + rr * 256u + sw * 16u);
+    if constexpr (AUX_ALT != Tune::kRowsAuxLd) __builtin_amdgcn_sched_barrier(0);     // (a convergent join: keeps the compiler from duplicating the staging code below into both arms)
     static_for<8>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4)) = x[k];
@@ -745,16 +580,16 @@ __device__ __forceinline__ void issue_preland_loads(u64* slice, BufRsrc src, uns
         __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (LdsVoidPtr)(slice + k * 128), 16, (k & 1) ? voff_odd : voff_even, k * 2048u + CH * 128u, 0, AUX);
     });
 }
-template <int CH, int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+template <int CH, int AUX_ALT = Tune::kRowsAuxLd>
 __device__ __forceinline__ void wave_preland_rows_half(u64* slice, BufRsrc src, bool alt = false)
 {
     const unsigned lane = fresh_lane_id();
     const unsigned sw = lane & 7, rr = lane >> 3;
     const unsigned voff_even = rr * 256u + ((sw ^ (rr >> 1)) << 4);       // row_swz(8 k + rr) = 4 (k & 1) | (rr >> 1)
     const unsigned voff_odd = voff_even ^ 64u;
-    if (AUX_ALT != MI355NTT_ROWS_AUX_LD && alt) issue_preland_loads<CH, AUX_ALT>(slice, src, voff_even, voff_odd);
-    else issue_preland_loads<CH, MI355NTT_ROWS_AUX_LD>(slice, src, voff_even, voff_odd);
-    if constexpr (AUX_ALT != MI355NTT_ROWS_AUX_LD) __builtin_amdgcn_sched_barrier(0);
+    if (AUX_ALT != Tune::kRowsAuxLd && alt) issue_preland_loads<CH, AUX_ALT>(slice, src, voff_even, voff_odd);
+    else issue_preland_loads<CH, Tune::kRowsAuxLd>(slice, src, voff_even, voff_odd);
+    if constexpr (AUX_ALT != Tune::kRowsAuxLd) __builtin_amdgcn_sched_barrier(0);
 }
 // (the caller has waited for the eight LDS-direct loads with a counted s_waitcnt vmcnt)
 __device__ __forceinline__ void wave_read_prelanded_half(u64 (&out)[16], const u64* slice)
@@ -774,7 +609,7 @@ __device__ __forceinline__ void wave_read_prelanded_half(u64 (&out)[16], const u
 // slice (wave_load_rows_half moves the same bytes memory -> VGPR -> ds_write_b128 -> slice), and the run-time choice of the cache policy
 // (alt) is a branch around eight instructions that define no register.  The slice must be idle (every earlier LDS access of this wave
 // retired); waits for everything this wave has in the vector-memory queue.
-template <int CH, int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+template <int CH, int AUX_ALT = Tune::kRowsAuxLd>
 __device__ __forceinline__ void wave_load_rows_half_direct(u64 (&out)[16], u64* slice, BufRsrc src, bool alt = false)
 {
     __builtin_amdgcn_sched_barrier(0);
@@ -784,70 +619,9 @@ __device__ __forceinline__ void wave_load_rows_half_direct(u64 (&out)[16], u64* 
     wave_read_prelanded_half(out, slice);
 }
 
-// lab (round 5): touch-prefetch of the next polynomial into L2.  gfx950 has no prefetch instruction and no null
-// destination; a scalar load into one SGPR that stays allocated until touch_wait() is the cheapest form that returns nothing to the
-// vector-memory queue (whose in-order return would put an HBM latency in front of every twiddle load issued behind it).  NC chunks
-// CSTRIDE bytes apart, NL lines LSTRIDE bytes apart in each, from byte OFF0 of `base` (wave-uniform).
-template <int NC, int CSTRIDE, int NL, int LSTRIDE, int OFF0 = 0>
-__device__ __forceinline__ void touch_lines_scalar(const void* base, unsigned& sink)
-{
-    const u64 b = reinterpret_cast<u64>(base);
-    const u32 lo = __builtin_amdgcn_readfirstlane(lo32(b)), hi = __builtin_amdgcn_readfirstlane(hi32(b));
-    const u64 sb = ((u64)hi << 32) | lo;
-    unsigned sk = sink;
-    static_for<NC * NL>([&sk, sb](auto ic) {
-        constexpr int i = decltype(ic)::value, off = OFF0 + (i / NL) * CSTRIDE + (i % NL) * LSTRIDE;
-        asm volatile("s_load_dword %0, %1, %2" : "+s"(sk) : "s"(sb), "n"(off));
-    });
-    sink = sk;
-}
-__device__ __forceinline__ void touch_wait(unsigned& sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink)); }
-
-// Both column halves' global loads issued back to back (16 x 16 B per lane in flight), then the two trips through the
-// slice: one exposed memory latency per polynomial instead of two.
-#ifndef MI355NTT_INV_MERGED_LOADS
-#define MI355NTT_INV_MERGED_LOADS 0
-#endif
-template <int AUX_ALT = MI355NTT_ROWS_AUX_LD>
-__device__ __forceinline__ void wave_load_rows_merged(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned, bool alt = false)
-{
-    const unsigned lane = fresh_lane_id();
-    char* base = reinterpret_cast<char*>(slice);
-    const unsigned sw = lane & 7, rr = lane >> 3;
-    v4u32 x[16];
-    (void)alt;                           // (lab form: both halves' loads at the default policy)
-    static_for<16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, k = i & 7, ch = i >> 3;
-        x[i] = __builtin_amdgcn_raw_buffer_load_b128(src, wave_byte_off + rr * 256u + sw * 16u, k * 2048u + ch * 128u, MI355NTT_ROWS_AUX_LD);
-    });
-    static_for<2>([&](auto cc) {
-        constexpr int ch = decltype(cc)::value;
-        static_for<8>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            *reinterpret_cast<v4u32*>(base + (8 * k + rr) * 128 + ((sw ^ row_swz(8 * k + rr)) << 4)) = x[8 * ch + k];
-        });
-        wave_lds_fence();
-        static_for<8>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(base + lane * 128 + ((m ^ row_swz(lane)) << 4));
-            v[16 * ch + 2 * m] = pr.x;
-            v[16 * ch + 2 * m + 1] = pr.y;
-        });
-        wave_lds_fence();
-    });
-}
-
-template <int AUX_ALT = MI355NTT_ROWS_AUX_LD>
+template <int AUX_ALT = Tune::kRowsAuxLd>
 __device__ __forceinline__ void wave_load_rows(u64 (&v)[32], u64* slice, BufRsrc src, unsigned wave_byte_off, unsigned lane, bool alt = false)
 {
-#ifdef MI355NTT_ABLATE_ROWS          // timing experiments only: no row loads (results are wrong)
-    static_for<32>([&](auto rc) { v[decltype(rc)::value] = (u64)fresh_lane_id() * 0x9E3779B97F4A7C15ULL + decltype(rc)::value; });
-    return;
-#endif
-    if constexpr (MI355NTT_INV_MERGED_LOADS) {
-        wave_load_rows_merged<AUX_ALT>(v, slice, src, wave_byte_off, lane, alt);
-        return;
-    }
     u64 h[16];
     wave_load_rows_half<0, AUX_ALT>(h, slice, src, wave_byte_off, lane, alt);
     static_for<16>([&](auto rc) { v[decltype(rc)::value] = h[decltype(rc)::value]; });
@@ -861,10 +635,7 @@ __device__ __forceinline__ void wave_load_rows(u64 (&v)[32], u64* slice, BufRsrc
 // The whole transform is straight-line code; without fences the scheduler hoists dozens of twiddle loads
 // (4 VGPRs each) and spills.  A scheduling fence every SCHED_GROUP butterflies bounds the live set; the
 // other three waves of the SIMD cover the load latency.
-#ifndef MI355NTT_SCHED_GROUP
-#define MI355NTT_SCHED_GROUP 4
-#endif
-constexpr int SCHED_GROUP = MI355NTT_SCHED_GROUP;
+constexpr int SCHED_GROUP = Tune::kSchedGroup;
 
 // k-th register index (k = 0..15) whose bit j is clear
 __host__ __device__ constexpr int low_reg(int j, int k) { return ((k >> j) << (j + 1)) | (k & ((1 << j) - 1)); }
@@ -872,19 +643,13 @@ __host__ __device__ constexpr int low_reg(int j, int k) { return ((k >> j) << (j
 // Twiddle ring of a round: GROUP butterflies per scheduling group, DEPTH buffers (the loads run DEPTH - 1 groups ahead).
 // VGPRs = 4 * GROUP * DEPTH.  The round at bit 0 reads lane-distinct entries that come from L2: smaller groups and a
 // deeper ring buy prefetch distance for the same registers.
-#ifndef MI355NTT_RING_GROUP_B0
-#define MI355NTT_RING_GROUP_B0 SCHED_GROUP
-#endif
-#ifndef MI355NTT_RING_DEPTH_B0
-#define MI355NTT_RING_DEPTH_B0 2
-#endif
 // TIGHT (exact-quotient general-prime inverse at n = 2^15: a full 64x64 high product and a 7-instruction partial reduction in
 // every stage need the registers): single butterflies, four buffers -- a prefetch distance of three butterflies out of 16
 // VGPRs instead of 32.
 template <int LOGN, int B, bool TIGHT = false>
 struct Ring {
-    static constexpr int GROUP = TIGHT ? 1 : (B == 0 && LOGN == 15) ? MI355NTT_RING_GROUP_B0 : SCHED_GROUP;
-    static constexpr int DEPTH = TIGHT ? 4 : (B == 0 && LOGN == 15) ? MI355NTT_RING_DEPTH_B0 : 2;
+    static constexpr int GROUP = TIGHT ? 1 : (B == 0 && LOGN == 15) ? Tune::kRingGroupB0 : SCHED_GROUP;
+    static constexpr int DEPTH = TIGHT ? 4 : (B == 0 && LOGN == 15) ? Tune::kRingDepthB0 : 2;
 };
 
 // Twiddles of butterfly group G of a round (GROUP butterflies per group, 16 / GROUP groups per stage).
@@ -903,19 +668,11 @@ __device__ __forceinline__ void load_tw_group(TwPair (&W)[GROUP], const TwPair* 
         constexpr int k = decltype(kc)::value;
         constexpr int r0 = low_reg(j, (G % GPS) * GROUP + k);
         constexpr unsigned u = (unsigned)r0 >> (j + 1);
-#ifdef MI355NTT_ABLATE_TWIDDLE
-        W[k].w = 0x123456789abcdefULL + r0; W[k].wp = 0xfedcba987654321ULL + j; (void)tw; (void)twr; (void)thi;
-#else
         if constexpr (B == Geo<LOGN>::B0) {                 // group index independent of the thread: scalar load
             if constexpr (SCALE && !FWD && zero_history(r0, j, JA)) W[k] = twn[len + u];
             else W[k] = tw[len + u];
         } else
-#ifdef MI355NTT_ABLATE_TWL1     // timing experiment: same loads, every address inside one 4 KiB window (always L1 hits)
-            W[k] = buf_load_tw(twr, (thi * 16u) & 0xff0u, (tw_dev_index(LOGN, B, j, len, 0, u) * 16u) & 0xff0u);
-#else
             W[k] = buf_load_tw(twr, thi * 16u, tw_dev_index(LOGN, B, j, len, 0, u) * 16u);
-#endif
-#endif
     });
 }
 
@@ -934,62 +691,172 @@ __device__ __forceinline__ void prio_hook(unsigned)
     if constexpr (PSPLIT >= 0 && G == PSPLIT) __builtin_amdgcn_s_setprio(PAFTER);
 }
 
-#ifndef MI355NTT_MAD_CHAIN
-#define MI355NTT_MAD_CHAIN 1
-#endif
-// Forward (CT) stages on register bits JHI..0 of a layout with register field at bit B.
-// PSPLIT / PAFTER: see prio_hook (-2 = no hook at all: kernels other than the n = 2^15 persistent ones).
-template <int LOGN, int HL, int B, int JHI, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0>
-__device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
+// ------------------------------------------------------------------------------------------------
+// kernel class HL_LIT: the reference's own arithmetic in the single-pass kernel shape (round 6)
+// ------------------------------------------------------------------------------------------------
+// The lazy classes above compute the exact transform; the reference reduces every product with singleBarrett's ONE conditional
+// subtraction (ntt_60bit.cuh:44-61), and for a Barrett-inexact modulus (hostparams.cpp, barrett_single_subtraction_exact) that leaves
+// q + r now and then, which the next butterfly's unsigned compares (:102-110, :166-178) turn into other words than the exact
+// transform's.  A drop-in has to return THOSE words, so the polynomials of such moduli -- and everything a raw call cannot verify --
+// used to run the stage-per-launch kernels of kernels_compat.hip: 2 passes over memory at n = 2^15, 0.10 of the HBM roofline.  Class
+// HL_LIT runs the same register-resident rounds with the reference's butterflies written out literally: three wide products per
+// butterfly (a psi, x1 mu, s q: `barrett_mul`, modarith.cuh -- the function the literal stage kernels call), the value carried from
+// stage to stage exactly as the reference's global / shared memory carries it (canonical, or q + r, or whatever a wrapped
+// subtraction made of it: every step is the same 64-bit operation on the same operands as ct_stage_kernel / gs_stage_kernel), a
+// halving in every GS stage instead of one scaling by n^-1, no canonicalisation at the end.  The butterfly network, the index
+// conventions and the device tables are those of the lazy classes (the .w half of a TwPair IS the reference's table entry); only the
+// order of the butterflies inside a stage differs, which no word depends on.  One read and one write of HBM per transform.
+constexpr int HL_LIT = 0;
+
+__device__ __forceinline__ u64 buf_load_w(BufRsrc r, u32 voff, u32 soff)          // the .w half of a TwPair entry (8 bytes)
 {
-#ifdef MI355NTT_ABLATE_COMPUTE       // timing experiments only (tools/kbench.hip): no butterflies at all -- results are wrong
-    return;
-#endif
-    constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
-    constexpr bool EX = Lazy<HL>::EXACT;
-    constexpr bool VEC = (B != Geo<LOGN>::B0);              // twiddles arrive in VGPRs: software-pipelined DEPTH - 1 groups ahead
+    const v2u32 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return (u64)x.x | ((u64)x.y << 32);
+}
+
+// twiddles (table entries, no companions) of butterfly group G of a literal round; indexing as load_tw_group
+template <int LOGN, int B, int JA, bool FWD, int GROUP, int G>
+__device__ __forceinline__ void load_w_group(u64 (&W)[GROUP], const TwPair* __restrict__ tw, BufRsrc twr, unsigned thi)
+{
+    constexpr int GPS = 16 / GROUP;
+    constexpr int j = FWD ? JA - G / GPS : JA + G / GPS;
+    constexpr int beta = B + j;
+    constexpr unsigned len = 1u << (LOGN - 1 - beta);
+    static_for<GROUP>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int r0 = low_reg(j, (G % GPS) * GROUP + k);
+        constexpr unsigned u = (unsigned)r0 >> (j + 1);
+        if constexpr (B == Geo<LOGN>::B0) W[k] = tw[len + u].w;                  // group index independent of the thread: scalar load
+        else W[k] = buf_load_w(twr, thi * 16u, tw_dev_index(LOGN, B, j, len, 0, u) * 16u);
+    });
+}
+
+// CTBasedNTTInner's butterfly (ntt_60bit.cuh:199-222): V = singleBarrett(a[j + step] psi); a[j] = U + V - q (U + V >= q);
+// a[j + step] = U + q (U < V) - V
+__device__ __forceinline__ void lit_ct_bfly(u64& a, u64& b, u64 w, const PrimeDev& p)
+{
+    const u64 U = a;
+    const u64 V = barrett_mul(b, w, p.q, p.mu, p.k);
+    a = add_mod(U, V, p.q);
+    b = sub_mod(U, V, p.q);
+}
+// GSBasedINTTInner's butterfly (:232-264): a[j] = half((U + V) mod q); a[j + step] = half(singleBarrett((U + q (U < V) - V) psiinv))
+__device__ __forceinline__ void lit_gs_bfly(u64& a, u64& b, u64 w, const PrimeDev& p, u64 q2)
+{
+    const u64 U = a, V = b;
+    a = half_mod(add_mod(U, V, p.q), q2);
+    b = half_mod(barrett_mul(sub_mod(U, V, p.q), w, p.q, p.mu, p.k), q2);
+}
+
+template <int LOGN, int B, int JHI, int PSPLIT = -2, int PAFTER = 0>
+__device__ __forceinline__ void ct_round_lit(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
+{
+    constexpr bool VEC = (B != Geo<LOGN>::B0);
     constexpr int GROUP = Ring<LOGN, B>::GROUP, DEPTH = Ring<LOGN, B>::DEPTH, GPS = 16 / GROUP, NG = (JHI + 1) * GPS;
-    const u64 cq = (u64)Lazy<HL>::TQ * p.q;
     const unsigned thi = t >> B;
-    TwPair W[DEPTH][GROUP];
+    u64 W[DEPTH][GROUP];
     static_for<DEPTH - 1>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
-        if constexpr (d < NG) load_tw_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi, nullptr);
+        if constexpr (d < NG) load_w_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi);
     });
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         constexpr int j = JHI - g / GPS;
-        constexpr int s = LOGN - 1 - (B + j);
-        constexpr bool red = (RMASK >> s) & 1u;
-        TwPair (&Wc)[GROUP] = W[g % DEPTH];
+        u64 (&Wc)[GROUP] = W[g % DEPTH];
         prio_hook<PSPLIT, PAFTER, g>(t);
-        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, nullptr);
+        if constexpr (g + DEPTH - 1 < NG) load_w_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
         static_for<GROUP>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
             constexpr int r1 = r0 | (1 << j);
-            u64 U = v[r0];
-            if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
-            if constexpr (!EX && MI355NTT_MAD_CHAIN) {
-                // (a, b) <- (U + T, U + cq - T): the sum comes out of the multiply-add accumulator, the difference is
-                // (2U + cq) - (U + T) (exact mod 2^64 even where 2U + cq wraps, because U + cq - T itself is below 2^64)
-                u64 D = (U << 1) + cq;
-                asm("" : "+v"(D));
-                const u64 A = mul_shoup4m_acc<!VEC>(v[r1], Wc[k].w, Wc[k].wp, p.nq, U);
-                v[r0] = A;
-                v[r1] = D - A;
-            } else if constexpr (EX || NEAR || LOGN != 15) {   // (smaller n: the extra live value costs a wave of occupancy)
-                const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
-                v[r0] = U + Tm;
-                v[r1] = U + cq - Tm;
-            } else {
-                v[r0] = U;
-                ct_bfly4(v[r0], v[r1], Wc[k].w, Wc[k].wp, p.nq, cq);
-            }
+            lit_ct_bfly(v[r0], v[r1], Wc[k], p);
         });
         if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
     });
+}
+
+template <int LOGN, int B, int JLO, int PSPLIT = -2, int PAFTER = 0>
+__device__ __forceinline__ void gs_round_lit(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
+{
+    constexpr bool VEC = (B != Geo<LOGN>::B0);
+    using RingT = Ring<LOGN, B, false>;
+    constexpr int GROUP = RingT::GROUP, DEPTH = RingT::DEPTH, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
+    const unsigned thi = t >> B;
+    const u64 q2 = (p.q + 1) >> 1;
+    u64 W[DEPTH][GROUP];
+    static_for<DEPTH - 1>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d < NG) load_w_group<LOGN, B, JLO, false, GROUP, d>(W[d], tw, twr, thi);
+    });
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int j = JLO + g / GPS;
+        u64 (&Wc)[GROUP] = W[g % DEPTH];
+        prio_hook<PSPLIT, PAFTER, g>(t);
+        if constexpr (g + DEPTH - 1 < NG) load_w_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi);
+        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+        static_for<GROUP>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
+            constexpr int r1 = r0 | (1 << j);
+            lit_gs_bfly(v[r0], v[r1], Wc[k], p, q2);
+        });
+        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// Forward (CT) stages on register bits JHI..0 of a layout with register field at bit B.
+// PSPLIT / PAFTER: see prio_hook (-2 = no hook at all: kernels other than the n = 2^15 persistent ones).
+template <int LOGN, int HL, int B, int JHI, bool NEAR = false, int PSPLIT = -2, int PAFTER = 0>
+__device__ __forceinline__ void ct_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p)
+{
+    if constexpr (HL == HL_LIT) {
+        ct_round_lit<LOGN, B, JHI, PSPLIT, PAFTER>(v, tw, twr, t, p);      // the reference's own butterflies
+    } else {
+        constexpr unsigned RMASK = fwd_reduce_mask<LOGN, HL>();
+        constexpr bool EX = Lazy<HL>::EXACT;
+        constexpr bool VEC = (B != Geo<LOGN>::B0);              // twiddles arrive in VGPRs: software-pipelined DEPTH - 1 groups ahead
+        constexpr int GROUP = Ring<LOGN, B>::GROUP, DEPTH = Ring<LOGN, B>::DEPTH, GPS = 16 / GROUP, NG = (JHI + 1) * GPS;
+        const u64 cq = (u64)Lazy<HL>::TQ * p.q;
+        const unsigned thi = t >> B;
+        TwPair W[DEPTH][GROUP];
+        static_for<DEPTH - 1>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if constexpr (d < NG) load_tw_group<LOGN, B, JHI, true, GROUP, d>(W[d], tw, twr, thi, nullptr);
+        });
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int j = JHI - g / GPS;
+            constexpr int s = LOGN - 1 - (B + j);
+            constexpr bool red = (RMASK >> s) & 1u;
+            TwPair (&Wc)[GROUP] = W[g % DEPTH];
+            prio_hook<PSPLIT, PAFTER, g>(t);
+            if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JHI, true, GROUP, g + DEPTH - 1>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, nullptr);
+            if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+            static_for<GROUP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
+                constexpr int r1 = r0 | (1 << j);
+                u64 U = v[r0];
+                if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
+                if constexpr (!EX) {
+                    // (a, b) <- (U + T, U + cq - T): the sum comes out of the multiply-add accumulator, the difference is
+                    // (2U + cq) - (U + T) (exact mod 2^64 even where 2U + cq wraps, because U + cq - T itself is below 2^64)
+                    u64 D = (U << 1) + cq;
+                    asm("" : "+v"(D));
+                    const u64 A = mul_shoup4m_acc<!VEC>(v[r1], Wc[k].w, Wc[k].wp, p.nq, U);
+                    v[r0] = A;
+                    v[r1] = D - A;
+                } else {
+                    const u64 Tm = mul_shoup<EX>(v[r1], Wc[k].w, Wc[k].wp, p.nq);
+                    v[r0] = U + Tm;
+                    v[r1] = U + cq - Tm;
+                }
+            });
+            if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+        });
+    }
 }
 
 // Inverse (GS) stages on register bits JLO..4 of a layout with register field at bit B.
@@ -999,81 +866,91 @@ template <int LOGN, int HL, int B, int JLO, bool NEAR = false, int PSPLIT = -2, 
 __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict__ tw, BufRsrc twr, unsigned t, const PrimeDev& p,
                                          const TwPair* __restrict__ twn)      // twn: &primes[idx].twn[0] -- read where it is used (last round only)
 {
-#ifdef MI355NTT_ABLATE_COMPUTE
-    return;
-#endif
-    constexpr InvPolicy<LOGN, HL> POL{};
-    static_assert(!IN2Q || (!Lazy<HL>::EXACT && B == 0 && JLO == 0), "lazy inputs: first round of a class with 4q of headroom only");
-    constexpr bool EX = Lazy<HL>::EXACT;
-    constexpr bool VEC = (B != Geo<LOGN>::B0);
-    using RingT = Ring<LOGN, B, false>;
-    constexpr int GROUP = RingT::GROUP, DEPTH = RingT::DEPTH, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
-    // The scaling by n^-1 (the reference halves in every stage, ntt_60bit.cuh:132,166,178) is folded into the twiddles of the
-    // LAST round: in stage j the butterflies whose register bits JLO .. j-1 are zero hold values that have only been summed in
-    // this round so far; their difference output takes twiddle * n^-1 (twn), every later butterfly of that output uses the
-    // plain table.  What has been summed in all stages -- the registers below 2^JLO -- is multiplied by n^-1 in the last stage:
-    // 2^JLO products per thread instead of 16.
-    constexpr bool SCALE = !VEC;
-    const unsigned thi = t >> B;
-    TwPair W[DEPTH][GROUP];
-    static_for<DEPTH - 1>([&](auto dc) {
-        constexpr int d = decltype(dc)::value;
-        if constexpr (d < NG) load_tw_group<LOGN, B, JLO, false, GROUP, d, SCALE>(W[d], tw, twr, thi, twn);
-    });
-    static_for<NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        constexpr int j = JLO + g / GPS;
-        constexpr int beta = B + j;             // index bit of this stage = GS stage number (0 = first)
-        constexpr bool last = (beta == LOGN - 1);
-        constexpr bool red = (POL.mask >> beta) & 1u;
-        const u64 cq = (u64)((IN2Q && beta == 0) ? 2 : POL.cmul[beta]) * p.q;
-        TwPair (&Wc)[GROUP] = W[g % DEPTH];
-        prio_hook<PSPLIT, PAFTER, g>(t);
-        if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1, SCALE>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, twn);
-        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
-        static_for<GROUP>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
-            constexpr int r1 = r0 | (1 << j);
-            const u64 X = v[r0], Y = v[r1];
-            u64 S = X + Y;
-            const u64 D = X + cq - Y;
-            // values entering canon_after_inverse: any multiple range for NEAR (it folds), below TQ*q otherwise
-            constexpr bool fin_red = last && !(NEAR && !EX) && (2 * POL.cmul[beta] > Lazy<HL>::TQ);
-            if constexpr (last && zero_history(r0, 5, JLO)) {
-                // summed in every stage of this round: the only values that still need an explicit n^-1
-                const TwPair ni = twn[0];
-                if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r0] = mul_shoup4m<true>(S, ni.w, ni.wp, p.nq);
-                else v[r0] = mul_shoup<EX>(S, ni.w, ni.wp, p.nq);
-            } else {
-                if constexpr (red || fin_red) {
-                    // exact-quotient class: S < 4q always, one conditional subtraction of 2q (5 instructions, no multiply, fewer
-                    // temporaries than the general partial reduction -- with it these kernels spilled)
-                    if constexpr (EX && !NEAR) S = csub(S, 2 * p.q);
-                    // general 61-bit primes (class 3, 8q < 2^64; round 5): a reducing stage sums two values below 4q, one conditional
-                    // subtraction of 4q restores the bound the policy assumes behind a reduction (max(TQ, 2) q = 4q) -- no multiply, no
-                    // reciprocal constants: with the 7-instruction general reduction the class-3 inverse and fused kernels spilled
-                    else if constexpr (HL == 3 && !NEAR) S = csub(S, 4 * p.q);
-                    else S = reduce_2q_sel<NEAR>(S, p);
-                }
-                v[r0] = S;
-            }
-            if constexpr (!EX && MI355NTT_MAD_CHAIN) v[r1] = mul_shoup4m<!VEC>(D, Wc[k].w, Wc[k].wp, p.nq);
-            else v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
+    if constexpr (HL == HL_LIT) {
+        gs_round_lit<LOGN, B, JLO, PSPLIT, PAFTER>(v, tw, twr, t, p);      // the reference's own butterflies
+    } else {
+        constexpr InvPolicy<LOGN, HL> POL{};
+        static_assert(!IN2Q || (!Lazy<HL>::EXACT && B == 0 && JLO == 0), "lazy inputs: first round of a class with 4q of headroom only");
+        constexpr bool EX = Lazy<HL>::EXACT;
+        constexpr bool VEC = (B != Geo<LOGN>::B0);
+        using RingT = Ring<LOGN, B, false>;
+        constexpr int GROUP = RingT::GROUP, DEPTH = RingT::DEPTH, GPS = 16 / GROUP, NG = (5 - JLO) * GPS;
+        // The scaling by n^-1 (the reference halves in every stage, ntt_60bit.cuh:132,166,178) is folded into the twiddles of the
+        // LAST round: in stage j the butterflies whose register bits JLO .. j-1 are zero hold values that have only been summed in
+        // this round so far; their difference output takes twiddle * n^-1 (twn), every later butterfly of that output uses the
+        // plain table.  What has been summed in all stages -- the registers below 2^JLO -- is multiplied by n^-1 in the last stage:
+        // 2^JLO products per thread instead of 16.
+        constexpr bool SCALE = !VEC;
+        const unsigned thi = t >> B;
+        TwPair W[DEPTH][GROUP];
+        static_for<DEPTH - 1>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if constexpr (d < NG) load_tw_group<LOGN, B, JLO, false, GROUP, d, SCALE>(W[d], tw, twr, thi, twn);
         });
-        if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
-    });
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int j = JLO + g / GPS;
+            constexpr int beta = B + j;             // index bit of this stage = GS stage number (0 = first)
+            constexpr bool last = (beta == LOGN - 1);
+            constexpr bool red = (POL.mask >> beta) & 1u;
+            const u64 cq = (u64)((IN2Q && beta == 0) ? 2 : POL.cmul[beta]) * p.q;
+            TwPair (&Wc)[GROUP] = W[g % DEPTH];
+            prio_hook<PSPLIT, PAFTER, g>(t);
+            if constexpr (g + DEPTH - 1 < NG) load_tw_group<LOGN, B, JLO, false, GROUP, g + DEPTH - 1, SCALE>(W[(g + DEPTH - 1) % DEPTH], tw, twr, thi, twn);
+            if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+            static_for<GROUP>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int r0 = low_reg(j, (g % GPS) * GROUP + k);
+                constexpr int r1 = r0 | (1 << j);
+                const u64 X = v[r0], Y = v[r1];
+                u64 S = X + Y;
+                const u64 D = X + cq - Y;
+                // values entering canon_after_inverse: any multiple range for NEAR (it folds), below TQ*q otherwise
+                constexpr bool fin_red = last && !(NEAR && !EX) && (2 * POL.cmul[beta] > Lazy<HL>::TQ);
+                if constexpr (last && zero_history(r0, 5, JLO)) {
+                    // summed in every stage of this round: the only values that still need an explicit n^-1
+                    const TwPair ni = twn[0];
+                    if constexpr (!EX) v[r0] = mul_shoup4m<true>(S, ni.w, ni.wp, p.nq);
+                    else v[r0] = mul_shoup<EX>(S, ni.w, ni.wp, p.nq);
+                } else {
+                    if constexpr (red || fin_red) {
+                        // exact-quotient class: S < 4q always, one conditional subtraction of 2q (5 instructions, no multiply, fewer
+                        // temporaries than the general partial reduction -- with it these kernels spilled)
+                        if constexpr (EX && !NEAR) S = csub(S, 2 * p.q);
+                        // general 61-bit primes (class 3, 8q < 2^64; round 5): a reducing stage sums two values below 4q, one conditional
+                        // subtraction of 4q restores the bound the policy assumes behind a reduction (max(TQ, 2) q = 4q) -- no multiply, no
+                        // reciprocal constants: with the 7-instruction general reduction the class-3 inverse and fused kernels spilled
+                        else if constexpr (HL == 3 && !NEAR) S = csub(S, 4 * p.q);
+                        else S = reduce_2q_sel<NEAR>(S, p);
+                    }
+                    v[r0] = S;
+                }
+                if constexpr (!EX) v[r1] = mul_shoup4m<!VEC>(D, Wc[k].w, Wc[k].wp, p.nq);
+                else v[r1] = mul_shoup<EX>(D, Wc[k].w, Wc[k].wp, p.nq);
+            });
+            if constexpr (VEC) __builtin_amdgcn_sched_barrier(0);
+        });
+    }
 }
 
+// (ct_round / gs_round above: class HL_LIT -> the literal butterflies, every other class -> the lazy ones.)
+// A context of class HL_LIT may hold Barrett-EXACT primes next to the inexact ones (the reference's own decryption_test.cu:47-48 set:
+// two exact, one not).  For those the reference's words are the exact transform's, so their polynomials take the lazy butterflies of
+// class HL_LIT_EXACT = 2 (exact quotients: valid for every q < 2^62; general partial reductions) -- the kernels branch per POLYNOMIAL
+// on PrimeDev::lit (wave-uniform, scalar) around the whole body of the polynomial loop (kernels_fast_impl.cuh, MI355NTT_BODY_PER_CLASS).
+constexpr int HL_LIT_EXACT = 6;
 // The pointwise step of the fused products: forward output x in [0, B q) times a word of bhat.  Near-2^k classes with 4q of
 // headroom: fold product, result in [0, 2q) (the inverse's first round then runs with IN2Q); otherwise Algorithm 7 on the
 // canonicalised value, result canonical.
 template <int HL, bool NEAR>
 struct FusedMul {
-    static constexpr bool LAZY = NEAR && !Lazy<HL>::EXACT;
+    static constexpr bool LAZY = HL != HL_LIT && NEAR && !Lazy<HL>::EXACT;
     __device__ static __forceinline__ u64 mul(u64 x, u64 b, const PrimeDev& p)
     {
-        if constexpr (LAZY) return mul_fold_near(reduce_2q_near(x, p), b, p);
+        // class HL_LIT: barrett_batch on what forwardNTT_batch left behind (poly_arithmetic.cuh:36-66; bfv_encryption.cuh:268-271) --
+        // the literal forward rounds' words as they are, the exact primes' lazy values canonicalised first
+        if constexpr (HL == HL_LIT) return barrett_mul(x, b, p.q, p.mu, p.k);
+        else if constexpr (LAZY) return mul_fold_near(reduce_2q_near(x, p), b, p);
         else return barrett_mul(canon_2q(reduce_2q_sel<NEAR>(x, p), p.q), b, p.q, p.mu, p.k);      // poly_arithmetic.cuh:36-66
     }
 };
@@ -1094,10 +971,8 @@ __device__ __forceinline__ void fwd_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             constexpr int TOPP = LOGN - 1 - 5 * (RHO - 1);
             constexpr int BP = TOPP - 4 > 0 ? TOPP - 4 : 0;
             exchange<LOGN, BP, B>(v, lds, t());
-            MI355NTT_STAMP(2 * RHO);
         }
         ct_round<LOGN, HL, B, TOP - B, NEAR>(v, tw, twr, t(), p);
-        MI355NTT_STAMP(2 * RHO + 1);
         fwd_rounds<LOGN, HL, RHO + 1, NEAR>(v, tw, twr, t, p, lds);
     }
 }
@@ -1120,10 +995,8 @@ __device__ __forceinline__ void inv_rounds(u64 (&v)[32], const TwPair* tw, BufRs
             constexpr int LOWP = 5 * (RHO - 1);
             constexpr int BP = LOWP < G::B0 ? LOWP : G::B0;
             exchange<LOGN, BP, B>(v, lds, t());
-            MI355NTT_STAMP(2 * RHO + 2);
         }
         gs_round<LOGN, HL, B, LOW - B, NEAR, -2, 0, (IN2Q && RHO == 0)>(v, tw, twr, t(), p, twn);
-        MI355NTT_STAMP(2 * RHO + 3);
         inv_rounds<LOGN, HL, RHO + 1, NEAR, IN2Q>(v, tw, twr, t, p, lds, twn);
     }
 }
@@ -1140,7 +1013,8 @@ __device__ __forceinline__ void inverse_core(u64 (&v)[32], const TwPair* tw, TID
 template <int HL, bool NEAR = false>
 __device__ __forceinline__ u64 canon_after_inverse(u64 x, const PrimeDev& p)
 {
-    if constexpr (!Lazy<HL>::EXACT) {
+    if constexpr (HL == HL_LIT) return x;           // (the reference stores what its last stage produced)
+    else if constexpr (!Lazy<HL>::EXACT) {
         if constexpr (NEAR) {
             x = reduce_2q_near(x, p);
         } else {
@@ -1149,6 +1023,13 @@ __device__ __forceinline__ u64 canon_after_inverse(u64 x, const PrimeDev& p)
         }
     }
     return canon_2q(x, p.q);
+}
+// forward outputs: [0, B q) -> [0, q)
+template <int HL, bool NEAR = false>
+__device__ __forceinline__ u64 canon_after_forward(u64 x, const PrimeDev& p)
+{
+    if constexpr (HL == HL_LIT) return x;
+    else return canon_2q(reduce_2q_sel<NEAR>(x, p), p.q);
 }
 
 }  // namespace mi355ntt

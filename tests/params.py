@@ -78,3 +78,30 @@ EDGE_PRIMES = {
     59: (576460752300015617, {65536: 296969298802020438, 32768: 178988506022562004, 4096: 379167746563934504}),
     30: (1073479681, {65536: 1070907127, 32768: 31849551, 4096: 371836615}),
 }
+
+# six 62-bit primes = 1 mod 2^17 just below 2^62 with primitive 8192-th roots (n = 4096), found by search (sympy.isprime, x^((q-1)/2n)
+# with w^n = -1), and the largest 40-bit prime: moduli WIDER than gamma, where a Barrett product mod gamma is no longer below 2 gamma
+# (the lazy sum of k_decrypt_round must fall back to the reference's per-term reduction)
+Q62_N4096 = [(4611686018425815041, 4411335539154205079), (4611686018423062529, 1987687080756694092), (4611686018422669313, 3419936153954982955),
+             (4611686018416115713, 1744709284562504997), (4611686018408120321, 1965406977792563506), (4611686018406940673, 1210959489459782225)]
+GAMMA40 = (1 << 40) - 87
+
+# Barrett-INEXACT primes (mi355ntt_barrett_is_exact == 0: the reference's single-subtraction Barrett returns q + r for some operand
+# pairs), = 1 mod 2^17, found by search (sympy.isprime + the host predicate): bits -> (q, {n: primitive 2n-th root}).  Such primes sit
+# in the upper part of [2^(k-1), 2^k) and far enough from 2^k that frac(2^(2k) / q) is large.
+INEXACT_PRIMES = {
+    34: (16717447169, {2048: 716892639, 4096: 10780603935, 8192: 9801559072, 16384: 14982407107, 32768: 14234614852, 65536: 3867875371}),
+    36: (66607251457, {2048: 399654466, 4096: 66172355353, 8192: 62832410156, 16384: 32337211720, 32768: 55503464023, 65536: 28050426572}),
+    50: (1090484111147009, {2048: 849604439456216, 4096: 275136633019418, 8192: 557074390833951, 16384: 863481998425754, 32768: 110572600602772,
+                            65536: 553978784588634}),
+    60: (1137833256315125761, {2048: 735943513308022933, 4096: 1024597489263776217, 8192: 418497743808556150, 16384: 206061080305443116,
+                               32768: 448230823712243253, 65536: 294981370794764583}),
+    61: (2248020882338086913, {2048: 163138043264649591, 4096: 1863497830520578066, 8192: 1290552877515215379, 16384: 896052032404846333,
+                               32768: 423556294508823369, 65536: 1593308822622025087}),
+}
+# Barrett-exact primes of similar size (same search, predicate true) to sit next to them in one context
+EXACT_NEIGHBOURS = {
+    36: (65803911169, {2048: 46725621650, 4096: 9944776363, 8192: 26729495459, 16384: 30672130432, 32768: 2091551950}),
+    60: (1137354327060774913, {2048: 168727745372988259, 4096: 1048799164746730205, 8192: 491669866052357047, 16384: 234609454235331695,
+                               32768: 492103990670350833}),
+}

@@ -109,6 +109,45 @@ def test_keygen_encrypt_decrypt_match_oracle_and_round_trip(native, oracle, gpu,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gamma", [P.GAMMA40, (1 << 50) - 27, P.GAMMA61])
+def test_decrypt_with_moduli_wider_than_gamma_matches_oracle(native, oracle, gpu, gamma):
+    """62-bit q_i next to a 40- / 50-bit gamma.  The base conversion's Barrett products mod gamma then exceed 2 gamma
+    (operands of 62 bits on a 40-bit Barrett), and a lazily summed accumulator would wrap where the reference's per-term `% gamma`
+    (poly_arithmetic.cuh:252) does not: every word decryption_rns leaves behind must still equal the oracle's, single and batched."""
+    import torch
+    from ntt_cuda_amd import bfv
+    n, t = 4096, 1024
+    qs, psis = [q for q, _ in P.Q62_N4096], [w for _, w in P.Q62_N4096]
+    R = len(qs)
+    ctx = bfv.BFVContext(n, qs, psis, t, gamma)
+    rng = np.random.default_rng(2024)
+    count = 3
+    c = np.stack([np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.uint64) for q in qs]) for _ in range(count)]) for _ in range(2)])   # [2][count][R][n]
+    sk_hat = oracle.bfv_sample(qs, n, 9)["uniform"]      # (the drivers take the key in the NTT domain: any residues serve)
+    want = []
+    for z_ in range(count):
+        w_c = np.ascontiguousarray(c[:, z_]).reshape(-1).copy()
+        w_m = np.empty(n, np.uint64)
+        oracle.lib().orc_bfv_decrypt(oracle._p(w_c), oracle._p(np.ascontiguousarray(sk_hat.reshape(-1)[: (R - 1) * n])), oracle._p(np.array(qs, np.uint64)),
+                                     oracle._p(np.array(psis, np.uint64)), R, n, t, gamma, oracle._p(w_m), None)
+        want.append((w_c, w_m))
+    d_sk = native.to_device(sk_hat)
+    for z_ in range(count):
+        d_c = native.to_device(np.ascontiguousarray(c[:, z_]))
+        got_m = ctx.decrypt(d_c, d_sk)
+        torch.cuda.synchronize()
+        assert np.array_equal(native.to_host(got_m), want[z_][1]), "plaintext words, ciphertext %d" % z_
+        assert np.array_equal(native.to_host(d_c).reshape(-1), want[z_][0]), "ciphertext words, ciphertext %d" % z_
+    d_cb = native.to_device(c)
+    ctx.decrypt_batch(d_cb, d_sk, count)
+    torch.cuda.synchronize()
+    got = native.to_host(d_cb).reshape(2, count, R, n)
+    for z_ in range(count):
+        assert np.array_equal(np.ascontiguousarray(got[:, z_]).reshape(-1), want[z_][0]), "batched driver, ciphertext %d" % z_
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,nprimes,count,literal", [(4096, 3, 5, False), (32768, 4, 7, False), (32768, 60, 64, False), (4096, 0, 3, True),
                                                      (65536, 2, 3, False)])
 def test_batched_drivers_equal_looped_single_calls(native, oracle, gpu, n, nprimes, count, literal):

@@ -1,0 +1,147 @@
+"""Round 6: kernel class 0 -- the reference's own arithmetic (singleBarrett with one conditional subtraction, the value carried from
+stage to stage as the reference's memory carries it, a halving in every inverse stage; ntt_60bit.cuh:44-61,199-222,232-264) in the
+single-pass, register-resident kernel shape (csrc/kernels_lit.cuh): contexts with a Barrett-inexact prime, every ring degree of the
+reference's dispatch, word for word against the oracle."""
+import numpy as np
+import pytest
+
+import params as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _adversarial(a, qs, rng):
+    """rows of {0, 1, q - 1, q - 2} (what ternary keys feed the transforms: the operand q - 1 is where the reference's Barrett
+    under-reduces most often) mixed into uniform residues"""
+    num, n = a.shape
+    for y in range(0, num, 3):
+        q = int(qs[y % len(qs)])
+        pick = rng.integers(0, 4, size=n)
+        a[y] = np.array([0, 1, q - 1, q - 2], dtype=np.uint64)[pick]
+    return a
+
+
+def _moduli(kind, n):
+    if kind == "inexact60":            # one Barrett-inexact 60-bit modulus: every polynomial through the literal butterflies
+        q, r = P.INEXACT_PRIMES[60]
+        return [q], [r[n]]
+    if kind == "mixed":                # inexact 36-bit, exact 60-bit, inexact 61-bit, exact 36-bit: both passes of a workgroup's walk
+        sel = [P.INEXACT_PRIMES[36], P.EXACT_NEIGHBOURS[60], P.INEXACT_PRIMES[61], P.EXACT_NEIGHBOURS[36]]
+        return [q for q, _ in sel], [r[n] for _, r in sel]
+    if kind == "inexact3":             # three inexact moduli of 34, 50 and 60 bits
+        sel = [P.INEXACT_PRIMES[34], P.INEXACT_PRIMES[50], P.INEXACT_PRIMES[60]]
+        return [q for q, _ in sel], [r[n] for _, r in sel]
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("kind", ["inexact60", "mixed", "inexact3"])
+def test_literal_class_matches_oracle_word_for_word(native, oracle, gpu, n, kind):
+    """forward, inverse and the fused product of a class-0 context: every word the oracle's, non-canonical ones included, for a few
+    polynomials and for a batch that makes the persistent workgroups walk more than one polynomial of each kind."""
+    import torch
+    qs, psis = _moduli(kind, n)
+    assert any(not native.barrett_is_exact(q) for q in qs)
+    ctx = native.NTTContext(n, qs, psis)
+    assert ctx.kernel_class == (0, False) or ctx.kernel_class == 0, ctx.kernel_class
+    assert ctx.literal_routing == (2 if kind == "mixed" else 1)
+    prm = oracle.Params(n, qs, psis)
+    rng = np.random.default_rng(n + len(qs))
+    per_cu = {2048: 16, 4096: 8, 8192: 4, 16384: 2, 32768: 1}[n]
+    big = 256 * per_cu * 2 + 5 * len(qs) + 1 if n <= 4096 else 256 * per_cu + 67      # beyond one polynomial per resident workgroup
+    seen_noncanonical = False
+    for num in (1, len(qs) + 2, big):
+        a = _adversarial(oracle.synth_batch(n, num, qs, 300 + num).reshape(num, n), qs, rng)
+        want_f = oracle.forward_batch(a.copy(), prm, threads=8).reshape(num, n)
+        d = native.to_device(a)
+        ctx.forward_batch(d, num)
+        torch.cuda.synchronize()
+        got = native.to_host(d).reshape(num, n)
+        bad = np.nonzero((got != want_f).any(axis=1))[0]
+        assert bad.size == 0, ("forward", n, kind, num, bad[:8])
+        qcol = np.array(qs, dtype=np.uint64)[np.arange(num) % len(qs)][:, None]
+        seen_noncanonical |= bool((want_f >= qcol).any())
+        ctx.inverse_batch(d, num)
+        want_i = oracle.inverse_batch(want_f.copy(), prm, threads=8).reshape(num, n)
+        got = native.to_host(d).reshape(num, n)
+        bad = np.nonzero((got != want_i).any(axis=1))[0]
+        assert bad.size == 0, ("inverse", n, kind, num, bad[:8])
+        if num != big or n <= 8192:
+            b = oracle.synth_batch(n, num, qs, 700 + num).reshape(num, n)
+            da = native.to_device(a)
+            ctx.polymul_batch(da, native.to_device(b), num)
+            want_m = oracle.inverse_batch(oracle.pointwise_batch(want_f, b, prm), prm, threads=8).reshape(num, n)
+            got = native.to_host(da).reshape(num, n)
+            bad = np.nonzero((got != want_m).any(axis=1))[0]
+            assert bad.size == 0, ("polymul", n, kind, num, bad[:8])
+    assert seen_noncanonical, "the reference's non-canonical words must be part of the expectation"
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [4096, 32768])
+def test_literal_class_follows_the_reference_on_arbitrary_words(native, oracle, gpu, n):
+    """A context whose primes are ALL inexact runs the literal butterflies on every polynomial: the same 64-bit operations on the
+    same operands as the reference's stage kernels, so even words that are no residues at all (q + r, 2^64 - 1, random 64-bit
+    patterns) come out as the oracle's."""
+    import torch
+    qs, psis = _moduli("inexact3", n)
+    ctx = native.NTTContext(n, qs, psis)
+    prm = oracle.Params(n, qs, psis)
+    rng = np.random.default_rng(5)
+    num = 7
+    a = rng.integers(0, 1 << 64, size=(num, n), dtype=np.uint64)
+    a[1] = np.uint64((1 << 64) - 1)
+    a[2] = np.array([int(qs[2]) + int(x) for x in rng.integers(0, 1000, size=n)], dtype=np.uint64)
+    for op, fn in (("forward", oracle.forward_batch), ("inverse", oracle.inverse_batch)):
+        d = native.to_device(a)
+        getattr(ctx, op + "_batch")(d, num)
+        torch.cuda.synchronize()
+        assert np.array_equal(native.to_host(d).reshape(num, n), fn(a.copy(), prm).reshape(num, n)), op
+    ctx.close()
+
+
+def test_raw_calls_on_an_inexact_modulus_run_the_single_pass_kernels(native, oracle, gpu):
+    """forwardNTT_batch / inverseNTT_batch with the caller's tables (ntt_60bit.cuh:608,652) on a set with a Barrett-inexact modulus:
+    the derived context is a class-0 one -- checked, trusted and captured calls all return the oracle's words; a table rewritten in
+    place sends the call to the guarded fallback leg."""
+    import torch
+    n = 32768
+    qs, psis = _moduli("mixed", n)
+    prm = oracle.Params(n, qs, psis)
+    mod = native.Moduli(qs)
+    tf = torch.from_numpy(prm.psi_tabs.view(np.int64).reshape(len(qs), n)).cuda()
+    ti = torch.from_numpy(prm.psiinv_tabs.view(np.int64).reshape(len(qs), n)).cuda()
+    num = 41
+    a = _adversarial(oracle.synth_batch(n, num, qs, 9).reshape(num, n), qs, np.random.default_rng(1))
+    want_f = oracle.forward_batch(a.copy(), prm, threads=8).reshape(num, n)
+    want_i = oracle.inverse_batch(want_f.copy(), prm, threads=8).reshape(num, n)
+    d = native.to_device(a)
+    native.forwardNTT_batch(d, n, tf, num, len(qs), mod)
+    assert native.raw_uses_fast_kernels(n, tf, mod)
+    assert np.array_equal(native.to_host(d).reshape(num, n), want_f)
+    native.inverseNTT_batch(d, n, ti, num, len(qs), mod)
+    assert np.array_equal(native.to_host(d).reshape(num, n), want_i)
+    # a table rewritten in place (another root): the checked call must follow the caller's table, not the cached context
+    psis2 = [pow(int(w), 3, int(q)) for w, q in zip(psis, qs)]
+    prm2 = oracle.Params(n, qs, psis2)
+    tf.copy_(torch.from_numpy(prm2.psi_tabs.view(np.int64).reshape(len(qs), n)))
+    d = native.to_device(a)
+    native.forwardNTT_batch(d, n, tf, num, len(qs), mod)
+    assert np.array_equal(native.to_host(d).reshape(num, n), oracle.forward_batch(a.copy(), prm2, threads=8).reshape(num, n))
+    native.raw_cache_clear()
+    # captured and replayed (no special case for contexts that mix exact and inexact primes any more)
+    tf.copy_(torch.from_numpy(prm.psi_tabs.view(np.int64).reshape(len(qs), n)))
+    d = native.to_device(a)
+    src = native.to_device(a)
+    native.forwardNTT_batch(d, n, tf, num, len(qs), mod)          # first sight outside the capture (derives the context)
+    torch.cuda.synchronize()
+    g, cs = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.graph(g, stream=cs):
+        native.forwardNTT_batch(d, n, tf, num, len(qs), mod)
+        native.inverseNTT_batch(d, n, ti, num, len(qs), mod)
+    for _ in range(2):
+        d.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(native.to_host(d).reshape(num, n), want_i)
+    native.raw_cache_clear()
