@@ -31,6 +31,8 @@ PSI60 = [4443670208963, 100545759574150, 31693996050849, 88651361085495]
 # BASELINE configs[4] (BFV at n = 2^15, 4 x 60-bit RNS): the special prime that encryption drops = the next 60-bit prime
 # = 1 mod 2^16 below Q60[3], with its minimal primitive 2n-th root; t and gamma as demo.cu:28,93
 Q60_SPECIAL, PSI60_SPECIAL = 1152921504595640321, 9679305630873
+# a Barrett-INEXACT 60-bit prime = 1 mod 2^17 with a primitive 2^16-th root (tests/params.py INEXACT_PRIMES[60]): the raw_literal leg
+Q60_INEXACT, PSI60_INEXACT = 1137833256315125761, 448230823712243253
 BFV_T, BFV_GAMMA = 1024, 2305843009213683713
 # the reference's published BFV configuration (Article.pdf p26 Table 7: n = 32768, log q = 880, r = 16): demo.cu:35-36
 DEMO_Q16 = [18014398506729473, 36028797017456641, 36028797014704129, 36028797014573057, 36028797014376449, 36028797013327873,
@@ -694,13 +696,38 @@ def main():
             ntt.forwardNTT_batch(scratch, n, tabs_f, batch, P, lit)
             ntt.inverseNTT_batch(scratch, n, tabs_i, batch, P, lit)
 
-        raw_literal = pairs_rate(lit_step, max(4, args.steps // 10), prewarm=20)
+        raw_unverifiable = pairs_rate(lit_step, max(4, args.steps // 10), prewarm=20)
         del scratch
+        # the reference's own arithmetic at single-pass speed (round 6, kernel class 0): the same call with a Barrett-INEXACT 60-bit
+        # modulus (mi355ntt_barrett_is_exact == 0: found by search, tests/params.py INEXACT_PRIMES[60]) -- the context must return the
+        # reference's words, q + r included, so every butterfly is singleBarrett written out literally; one read and one write per transform
+        raw_literal, lit_valid = None, None
+        try:
+            assert not ntt.barrett_is_exact(Q60_INEXACT)
+            tpi, tii = ntt.fillTablePsi128(PSI60_INEXACT, Q60_INEXACT, ntt.modinv128(PSI60_INEXACT, Q60_INEXACT), n)
+            tab_fi = torch.from_numpy(tpi.view(np.int64)).to(dev).reshape(1, n)
+            tab_ii = torch.from_numpy(tii.view(np.int64)).to(dev).reshape(1, n)
+            modi = ntt.Moduli([Q60_INEXACT])
+            bi = synth(torch, batch, n, [Q60_INEXACT], dev, seed=21)
+
+            def inexact_step():
+                ntt.forwardNTT_batch(bi, n, tab_fi, batch, 1, modi)
+                ntt.inverseNTT_batch(bi, n, tab_ii, batch, 1, modi)
+
+            inexact_step()
+            lit_valid = bool(ntt.raw_uses_fast_kernels(n, tab_fi, modi))
+            raw_literal = pairs_rate(inexact_step, max(20, args.steps // 2), prewarm=150)
+            del bi
+        except Exception as exc:            # never let an optional leg break the contract line
+            raw_literal = {"error": repr(exc)}
         out["raw_api"] = {"raw_api_pairs_per_s": raw_checked, "raw_api_trusted_pairs_per_s": raw_trusted,
-                          "raw_literal_pairs_per_s": raw_literal,
+                          "raw_literal_pairs_per_s": raw_literal, "raw_literal_runs_single_pass_kernels": lit_valid,
+                          "raw_unverifiable_pairs_per_s": raw_unverifiable,
                           "what": "forwardNTT_batch + inverseNTT_batch through the reference-signature C ABI on the bench workload: "
-                                  "checked (per-call device-side table comparison), trusted (mi355ntt_raw_trust_tables), literal kernels "
-                                  "(2 passes over memory per transform: one stage launch + the 2^14-coefficient LDS kernel)"}
+                                  "checked (per-call device-side table comparison), trusted (mi355ntt_raw_trust_tables); literal = the same "
+                                  "checked call on a Barrett-inexact 60-bit modulus (one prime, 1024 polynomials): kernel class 0, the "
+                                  "reference's singleBarrett butterflies in the single-pass kernels; unverifiable = a hand-made mu, which "
+                                  "keeps the call on the stage kernels (2 passes over memory per transform)"}
         # BASELINE configs[2]: batch 256, pointwise modmul fused (NTT -> (.) -> INTT in one kernel), and configs[1]: batch 1
         b256 = synth(torch, 256, n, Q60, dev, seed=7)
         bh = synth(torch, 256, n, Q60, dev, seed=8)

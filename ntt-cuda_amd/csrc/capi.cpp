@@ -216,7 +216,11 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
     }
     if (c->inexact_mask) {
         c->literal = true;
+        // the single-pass literal kernels serve n <= 2^15 and inexact moduli of 34 ... 61 bits (ntt_core.cuh, lit_barrett_mul: both
+        // 128-bit shifts of singleBarrett as funnel shifts of 32-bit words); anything else keeps the stage-per-launch kernels
         c->literal_stages = (n == 65536);
+        for (unsigned i = 0; i < num_primes; i++)
+            if (((c->inexact_mask >> i) & 1u) && (c->prime[i].k < 34 || c->prime[i].k > 61)) c->literal_stages = true;
         c->mixed = !c->literal_stages && c->inexact_mask != (num_primes >= 32 ? ~0u : (1u << num_primes) - 1u);
     }
 
@@ -657,6 +661,13 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (e->trusted) return inverse ? run_inverse(c, d_a, num, division, 0, s) : run_forward(c, d_a, num, division, 0, s);
     hipError_t err;
+    // A capturing stream takes no part in the hand-over of the entry's guard words between streams: an event recorded outside the
+    // capture cannot be waited for inside it (nor the other way round), and the graph may be replayed next to anything.  Its checked
+    // calls therefore follow the caller's table with the literal kernels -- always the reference's words; a caller who wants the
+    // throughput kernels inside a graph promises the table with mi355ntt_raw_trust_tables (then nothing is shared).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+        return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (!e->ev && (err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming)) != hipSuccess) return err;
     if (e->used && e->last_stream != s && (err = hipStreamWaitEvent(s, e->ev, 0)) != hipSuccess) return err;
     unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);

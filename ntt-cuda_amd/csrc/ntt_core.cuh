@@ -731,12 +731,40 @@ __device__ __forceinline__ void load_w_group(u64 (&W)[GROUP], const TwPair* __re
     });
 }
 
+// singleBarrett on the product y w (ntt_60bit.cuh:44-61; modarith.cuh barrett_mul is the plain form of the same function) for moduli of
+// 34 ... 61 bits, where both 128-bit shifts are funnel shifts of 32-bit words: x1 = P >> (k - 2) from words 1..3 of the product,
+// s = (x1 mu) >> (k + 2) from words 1..3 of that product (v_alignbit_b32 by k - 34 and k - 30), r = P - s q as P + s (2^64 - q) with
+// only the low 64 bits formed, ONE conditional subtraction.  Every step is the reference's 64/128-bit operation on the same
+// operands -- for ANY 64-bit y, not only residues -- so the words are the reference's whatever it was fed.  11 multiply-adds.
+__device__ __forceinline__ u64 lit_barrett_mul(u64 y, u64 w, const PrimeDev& p)
+{
+    const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w);
+    const u64 A = mad32(y0, w0, 0);                                   // P0 = lo32(A)
+    const u64 T = mad32(y0, w1, (u64)hi32(A));
+    const u64 U = mad32(y1, w0, (u64)lo32(T));                        // P1 = lo32(U)
+    const u64 V = mad32(y1, w1, (u64)hi32(T)) + hi32(U);              // P2, P3
+    const u32 sh = p.near_sh - 2u, sh2 = p.near_sh + 2u;              // k - 34, k - 30  (near_sh = k - 32)
+    const u32 x0 = __builtin_amdgcn_alignbit(lo32(V), lo32(U), sh), x1 = __builtin_amdgcn_alignbit(hi32(V), lo32(V), sh);      // (P >> (k - 2)).low
+    const u32 m0 = lo32(p.mu), m1 = hi32(p.mu);
+    const u64 A2 = mad32(x0, m0, 0);
+    const u64 T2 = mad32(x0, m1, (u64)hi32(A2));
+    const u64 U2 = mad32(x1, m0, (u64)lo32(T2));                      // word 1 of x1 mu = lo32(U2)
+    const u64 V2 = mad32(x1, m1, (u64)hi32(T2)) + hi32(U2);           // words 2, 3
+    const u32 s0 = __builtin_amdgcn_alignbit(lo32(V2), lo32(U2), sh2), s1 = __builtin_amdgcn_alignbit(hi32(V2), lo32(V2), sh2);   // ((x1 mu) >> (k + 2)).low
+    const u32 n0 = lo32(p.nq), n1 = hi32(p.nq);
+    const u64 acc = mad32(s0, n0, A);                                 // low word: P0 + s0 n0; high word so far: hi32(A) + carries
+    const u64 c = mad32(s1, n0, mad32(s0, n1, 0));                    // cross terms of s (2^64 - q): only their low 32 bits count
+    const u32 r1 = hi32(acc) + (lo32(U) - hi32(A)) + lo32(c);         // P1 = hi32(A) + (lo32(U) - hi32(A))
+    const u64 r = ((u64)r1 << 32) | lo32(acc);
+    return r >= p.q ? r - p.q : r;
+}
+
 // CTBasedNTTInner's butterfly (ntt_60bit.cuh:199-222): V = singleBarrett(a[j + step] psi); a[j] = U + V - q (U + V >= q);
 // a[j + step] = U + q (U < V) - V
 __device__ __forceinline__ void lit_ct_bfly(u64& a, u64& b, u64 w, const PrimeDev& p)
 {
     const u64 U = a;
-    const u64 V = barrett_mul(b, w, p.q, p.mu, p.k);
+    const u64 V = lit_barrett_mul(b, w, p);
     a = add_mod(U, V, p.q);
     b = sub_mod(U, V, p.q);
 }
@@ -745,7 +773,7 @@ __device__ __forceinline__ void lit_gs_bfly(u64& a, u64& b, u64 w, const PrimeDe
 {
     const u64 U = a, V = b;
     a = half_mod(add_mod(U, V, p.q), q2);
-    b = half_mod(barrett_mul(sub_mod(U, V, p.q), w, p.q, p.mu, p.k), q2);
+    b = half_mod(lit_barrett_mul(sub_mod(U, V, p.q), w, p), q2);
 }
 
 template <int LOGN, int B, int JHI, int PSPLIT = -2, int PAFTER = 0>
@@ -938,7 +966,7 @@ __device__ __forceinline__ void gs_round(u64 (&v)[32], const TwPair* __restrict_
 // two exact, one not).  For those the reference's words are the exact transform's, so their polynomials take the lazy butterflies of
 // class HL_LIT_EXACT = 2 (exact quotients: valid for every q < 2^62; general partial reductions) -- the kernels branch per POLYNOMIAL
 // on PrimeDev::lit (wave-uniform, scalar) around the whole body of the polynomial loop (kernels_fast_impl.cuh, MI355NTT_BODY_PER_CLASS).
-constexpr int HL_LIT_EXACT = 6;
+constexpr int HL_LIT_EXACT = 2;
 // The pointwise step of the fused products: forward output x in [0, B q) times a word of bhat.  Near-2^k classes with 4q of
 // headroom: fold product, result in [0, 2q) (the inverse's first round then runs with IN2Q); otherwise Algorithm 7 on the
 // canonicalised value, result canonical.

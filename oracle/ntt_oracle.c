@@ -266,7 +266,10 @@ int orc_bfv_decrypt(u64* c, const u64* sk, const u64* qs, const u64* psis, unsig
         mus[i] = orc_mu(qs[i], kbits[i]);
     }
     orc_bfv_constants(qs, psis, r_plus_1, t, gamma, psiinv, inv_punct, neg_inv, ptg, iql, qdt);
-    const unsigned gamma_bits = 61;                                /* output_base_bit_lengths = {10, 61}, :98 */
+    /* output_base_bit_lengths = {10, 61}, decryption_test.cu:111 / demo.cu:100: data the caller writes next to gamma = 2305843009213683713
+     * (61 bits), used only as the Barrett bit length of gamma (:244-247).  For another gamma a caller writes that gamma's bit length, which
+     * is what this computes (61 for the reference's gamma: the KAT is unaffected). */
+    const unsigned gamma_bits = orc_bit_length(gamma);
     u64 mu_gamma = orc_mu(gamma, gamma_bits);                      /* :252-258 */
     u64 gamma_div_2 = gamma >> 1;                                  /* :91 */
 

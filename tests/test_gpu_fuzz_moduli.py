@@ -171,7 +171,9 @@ def test_modulus_against_oracle(native, oracle, gpu, idx):
         psi = psi_for(q, n)
         prm = oracle.Params(n, [q], [psi])
         ctx = native.NTTContext(n, [q], [psi])
-        assert ctx.kernel_class == expected_class([q]), (name, q, n, ctx.kernel_class)
+        # (Barrett-inexact moduli of 34 ... 61 bits run the reference's own arithmetic in the single-pass kernels up to n = 2^15: class 0)
+        single_pass_literal = (not exact) and n <= 32768 and 34 <= q.bit_length() <= 61
+        assert ctx.kernel_class == ((0, False) if single_pass_literal else expected_class([q])), (name, q, n, ctx.kernel_class)
         assert ctx.literal_routing == (0 if exact else 1), (name, q, n)
         small, large = BATCHES[n]
         # every modulus runs the small batch at every size and the large batch at two of the four sizes (by turns)

@@ -74,7 +74,8 @@ def test_literal_class_matches_oracle_word_for_word(native, oracle, gpu, n, kind
             got = native.to_host(da).reshape(num, n)
             bad = np.nonzero((got != want_m).any(axis=1))[0]
             assert bad.size == 0, ("polymul", n, kind, num, bad[:8])
-    assert seen_noncanonical, "the reference's non-canonical words must be part of the expectation"
+    if kind == "inexact60":     # (how often the reference under-reduces depends on frac(2^(2k) / q): this modulus does on every batch)
+        assert seen_noncanonical, "the reference's non-canonical words must be part of the expectation"
     ctx.close()
 
 
@@ -129,11 +130,13 @@ def test_raw_calls_on_an_inexact_modulus_run_the_single_pass_kernels(native, ora
     native.forwardNTT_batch(d, n, tf, num, len(qs), mod)
     assert np.array_equal(native.to_host(d).reshape(num, n), oracle.forward_batch(a.copy(), prm2, threads=8).reshape(num, n))
     native.raw_cache_clear()
-    # captured and replayed (no special case for contexts that mix exact and inexact primes any more)
+    # captured and replayed: checked calls inside a capture follow the caller's table with the literal stage kernels, trusted ones run
+    # the single-pass kernels (nothing is shared between the graph and other streams then) -- the same words both ways
     tf.copy_(torch.from_numpy(prm.psi_tabs.view(np.int64).reshape(len(qs), n)))
     d = native.to_device(a)
     src = native.to_device(a)
-    native.forwardNTT_batch(d, n, tf, num, len(qs), mod)          # first sight outside the capture (derives the context)
+    native.forwardNTT_batch(d, n, tf, num, len(qs), mod)          # first sight outside the capture (derives the contexts)
+    native.inverseNTT_batch(d, n, ti, num, len(qs), mod)
     torch.cuda.synchronize()
     g, cs = torch.cuda.CUDAGraph(), torch.cuda.Stream()
     with torch.cuda.graph(g, stream=cs):
@@ -142,6 +145,16 @@ def test_raw_calls_on_an_inexact_modulus_run_the_single_pass_kernels(native, ora
     for _ in range(2):
         d.copy_(src)
         g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(native.to_host(d).reshape(num, n), want_i)
+    assert native.raw_trust_tables(n, tf, mod) and native.raw_trust_tables(n, ti, mod, inverse=True)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=cs):
+        native.forwardNTT_batch(d, n, tf, num, len(qs), mod)
+        native.inverseNTT_batch(d, n, ti, num, len(qs), mod)
+    for _ in range(2):
+        d.copy_(src)
+        g2.replay()
         torch.cuda.synchronize()
         assert np.array_equal(native.to_host(d).reshape(num, n), want_i)
     native.raw_cache_clear()
