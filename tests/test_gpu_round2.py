@@ -117,8 +117,7 @@ def test_raw_api_falls_back_to_literal_kernels(native, oracle, gpu):
     assert not native.raw_trust_tables(n, d_tp, mod2)      # nothing to trust: a hand-made mu stays on the literal kernels
     # (3) the untouched table still routes to the throughput kernels.  A set that MIXES moduli on which the reference's Barrett is
     # exact with one on which it is not -- the reference's own decryption_test.cu:47-48 set, prime 1 -- is routed per prime since
-    # round 5 (the derived context is a mixed one: two of three primes on the throughput kernels); a call whose moduli are ALL
-    # inexact stays on the literal kernels
+    # round 5 (the derived context is a mixed one: two of three primes on the lazy butterflies, one on the literal ones)
     assert native.raw_uses_fast_kernels(n, d_tp, mod)
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat1_decryption_n4096.npz"))
     kn, kq = int(z["n"]), [int(x) for x in z["q"]]
@@ -126,7 +125,13 @@ def test_raw_api_falls_back_to_literal_kernels(native, oracle, gpu):
     d_kt, d_kti, kmod = dev(native, kp.psi_tabs), dev(native, kp.psiinv_tabs), native.Moduli(z["q"])
     assert native.raw_uses_fast_kernels(kn, d_kt, kmod)
     one = oracle.Params(kn, kq[1:2], [int(z["psi"][1])])
-    assert not native.raw_uses_fast_kernels(kn, dev(native, one.psi_tabs), native.Moduli(kq[1:2]))
+    # (round 6: a call whose moduli are ALL inexact runs the single-pass kernels too -- kernel class 0, the reference's own butterflies)
+    d_one = dev(native, one.psi_tabs)
+    assert native.raw_uses_fast_kernels(kn, d_one, native.Moduli(kq[1:2]))
+    oa = oracle.synth_batch(kn, 5, kq[1:2], 31)
+    d_oa = dev(native, oa)
+    native.forwardNTT_batch(d_oa, kn, d_one, 5, 1, native.Moduli(kq[1:2]))
+    assert np.array_equal(host(native, d_oa), oracle.forward_batch(oa, one, threads=THREADS))
     # ... with the reference's words for every prime: checked calls, a table rewritten in place under them (the literal share of the
     # mixed context must stand back as well: inverted guard pair), ragged batches over several chunks of the gather buffer, trusted calls
     for knum in (3, 7, 902):
