@@ -57,6 +57,7 @@ struct mi355ntt_ctx {
     //                     of kernels_compat.hip;
     //   mixed          -- some, not all, primes inexact (reported by mi355ntt_ctx_uses_literal_kernels as 2; routing as `literal`).
     bool literal = false, literal_stages = false, mixed = false;
+    bool in_kernel_check = false;      // raw-cache contexts only: the guard record knows the entry's table (fast_guard_setup)
     unsigned inexact_mask = 0;
     // n = 2^16 (beyond the reference's dispatch): stage 1 splits the transform into two independent half-size ones whose
     // stage `L` reads table entries [2L + h L, 2L + (h + 1) L) -- an ordinary 2^15 transform on a derived table.  `fast`
@@ -80,7 +81,7 @@ static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
 // table / modulus indexing of the stage-launch legs below uses the plain index pb.
 static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
-    const unsigned pb = base & ~kGuardBit;
+    const unsigned pb = base & ~(kGuardBit | kCheckInKernelBit);
     if (c->literal_stages) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)pb * c->n, num, division, mods_from(c, pb, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides in the loads of the lower halves' launch (1.5 passes over memory instead of 2)
@@ -94,7 +95,7 @@ static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, uns
 
 static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
-    const unsigned pb = base & ~kGuardBit;
+    const unsigned pb = base & ~(kGuardBit | kCheckInKernelBit);
     if (c->literal_stages) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)pb * c->n, num, division, mods_from(c, pb, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides behind the lower halves' last round (1.5 passes over memory instead of 2)
@@ -603,6 +604,11 @@ mi355ntt_ctx* raw_derive(int device, unsigned n, unsigned division, bool inverse
         mi355ntt_ctx_destroy(c);
         return nullptr;
     }
+    // the entry's table and the context's, for the comparison inside the n = 2^15 launches (fails softly: those calls then keep the
+    // comparison kernel in front of the transform)
+    c->in_kernel_check = !c->literal_stages && !c->split16 &&
+                         fast_guard_setup(c->fast, d_tab, inverse ? c->d_psiinv : c->d_psi, division) == hipSuccess;
+    (void)hipGetLastError();
     return c;
 }
 
@@ -671,10 +677,33 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
     if (!e->ev && (err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming)) != hipSuccess) return err;
     if (e->used && e->last_stream != s && (err = hipStreamWaitEvent(s, e->ev, 0)) != hipSuccess) return err;
     unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);
-    if (++e->epoch == 0) e->epoch = 1;
-    if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s)) != hipSuccess) return err;
-    err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
-    if (err != hipSuccess) return err;
+    // n = 2^15, a batch the persistent kernels run: the transform's own workgroups compare the tables (checked_entry,
+    // kernels_fast_impl.cuh) -- one launch and no dependent read in front of the transform.  Its workgroups wait for each other, so
+    // the launch takes the device's pair-flag slot; when the slot is not to be had (another stream's waiting kernel in flight, a
+    // stream restricted to part of the CUs) the call keeps the comparison kernel in front.
+    bool done = false;
+    if (c->in_kernel_check && fast_in_kernel_check_ok(c->fast, num, division)) {
+        hipError_t st = hipSuccess;
+        if (PairSlot* slot = pair_acquire(s, &st)) {
+            err = inverse ? run_inverse(c, d_a, num, division, kGuardBit | kCheckInKernelBit, s) : run_forward(c, d_a, num, division, kGuardBit | kCheckInKernelBit, s);
+            pair_release(slot, s);
+            if (err != hipSuccess) return err;
+            done = true;
+        } else if (st != hipSuccess) {
+            // an earlier waiting kernel on this device gave up (reported here, nothing launched).  A checked launch that was in flight
+            // then may have left its arrival words behind: every cached entry's are zeroed in stream order before the error goes out
+            for (RawEntry& o : g_raw_cache)
+                if (o.ctx && o.ctx->in_kernel_check)
+                    (void)hipMemsetAsync(static_cast<char*>(o.ctx->fast.d_primes_alloc) + 32, 0, 12, s);      // GuardRec::arrive, depart, differ
+            return st;
+        }
+    }
+    if (!done) {
+        if (++e->epoch == 0 || e->epoch >= 0xfffffff0u) e->epoch = 1;
+        if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s)) != hipSuccess) return err;
+        err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
+        if (err != hipSuccess) return err;
+    }
     err = inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s, guard) : compat_forward_batch(d_a, n, d_tab, num, division, m, s, guard);
     if (err != hipSuccess) return err;
     e->used = true;

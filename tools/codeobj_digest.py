@@ -101,10 +101,20 @@ def main():
             old.update(digests(p))
         for p in args[2].split(","):
             new.update(digests(p))
-        names = subprocess.run(["c++filt"], input="\n".join(sorted(set(old) | set(new))), capture_output=True, text=True).stdout.splitlines()
+        def by_name(d):
+            names = subprocess.run(["c++filt"], input="\n".join(d), capture_output=True, text=True).stdout.splitlines()
+            out = {}
+            for (raw, v), nm in zip(d.items(), names):
+                nm = re.sub(r"\(.*", "", nm).replace("void ", "").replace("mi355ntt::", "")
+                # (round 6 appended a defaulted template argument CHECKED = false to k_forward15 / k_inverse15: the same kernels)
+                nm = re.sub(r"^(k_forward15<\d, (?:true|false), \d), false>$", r"\1>", nm)
+                nm = re.sub(r"^(k_inverse15<\d, (?:true|false)), false>$", r"\1>", nm)
+                out[nm] = v
+            return out
+        old, new = by_name(old), by_name(new)
         bad = 0
-        for raw, nm in zip(sorted(set(old) | set(new)), names):
-            nm = re.sub(r"\(.*", "", nm).replace("void ", "").replace("mi355ntt::", "")
+        for raw in sorted(set(old) | set(new)):
+            nm = raw
             if raw not in old:
                 print("NEW      %6d  %s" % (new[raw][1], nm))
             elif raw not in new:
