@@ -57,7 +57,6 @@ struct mi355ntt_ctx {
     //                     of kernels_compat.hip;
     //   mixed          -- some, not all, primes inexact (reported by mi355ntt_ctx_uses_literal_kernels as 2; routing as `literal`).
     bool literal = false, literal_stages = false, mixed = false;
-    bool in_kernel_check = false;      // raw-cache contexts only: the guard record knows the entry's table (fast_guard_setup)
     unsigned inexact_mask = 0;
     // n = 2^16 (beyond the reference's dispatch): stage 1 splits the transform into two independent half-size ones whose
     // stage `L` reads table entries [2L + h L, 2L + (h + 1) L) -- an ordinary 2^15 transform on a derived table.  `fast`
@@ -81,7 +80,7 @@ static ModSet mods_from(const mi355ntt_ctx* c, unsigned base, unsigned division)
 // table / modulus indexing of the stage-launch legs below uses the plain index pb.
 static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
-    const unsigned pb = base & ~(kGuardBit | kCheckInKernelBit);
+    const unsigned pb = base & ~kGuardBit;
     if (c->literal_stages) return compat_forward_batch(d_a, c->n, c->d_psi + (size_t)pb * c->n, num, division, mods_from(c, pb, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides in the loads of the lower halves' launch (1.5 passes over memory instead of 2)
@@ -95,7 +94,7 @@ static hipError_t run_forward(const mi355ntt_ctx* c, u64* d_a, unsigned num, uns
 
 static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, unsigned division, unsigned base, hipStream_t s)
 {
-    const unsigned pb = base & ~(kGuardBit | kCheckInKernelBit);
+    const unsigned pb = base & ~kGuardBit;
     if (c->literal_stages) return compat_inverse_batch(d_a, c->n, c->d_psiinv + (size_t)pb * c->n, num, division, mods_from(c, pb, division), s);
     if (c->split16) {
         // large batches: the coupling stage rides behind the lower halves' last round (1.5 passes over memory instead of 2)
@@ -543,9 +542,14 @@ struct RawEntry {
     // checked mode (default): the table is compared with the context's in front of every transform (guard words, kernels.hpp)
     bool trusted = false;              // the caller promised not to rewrite the table: no per-call comparison
     unsigned epoch = 0;
-    hipEvent_t ev = nullptr;           // last use of the guard words, for calls that arrive on another stream
+    hipEvent_t ev = nullptr;           // hand-over of the guard words to a call that arrives on another stream (recorded then, not per call)
     hipStream_t last_stream = nullptr;
     bool used = false;
+    // host-mapped word the comparison kernel sets when the table no longer holds what the context was derived from: the next call
+    // derives a new context (twice; an entry whose table keeps changing then stays on the literal kernels)
+    volatile unsigned* h_changed = nullptr;
+    unsigned* d_changed = nullptr;
+    unsigned rederived = 0;
 };
 
 std::mutex g_raw_mutex;
@@ -604,11 +608,6 @@ mi355ntt_ctx* raw_derive(int device, unsigned n, unsigned division, bool inverse
         mi355ntt_ctx_destroy(c);
         return nullptr;
     }
-    // the entry's table and the context's, for the comparison inside the n = 2^15 launches (fails softly: those calls then keep the
-    // comparison kernel in front of the transform)
-    c->in_kernel_check = !c->literal_stages && !c->split16 &&
-                         fast_guard_setup(c->fast, d_tab, inverse ? c->d_psiinv : c->d_psi, division) == hipSuccess;
-    (void)hipGetLastError();
     return c;
 }
 
@@ -616,8 +615,11 @@ void raw_entry_release(RawEntry& e)
 {
     if (e.ctx) mi355ntt_ctx_destroy(e.ctx);
     if (e.ev) (void)hipEventDestroy(e.ev);
+    if (e.h_changed) (void)hipHostFree(const_cast<unsigned*>(e.h_changed));
     e.ctx = nullptr;
     e.ev = nullptr;
+    e.h_changed = nullptr;
+    e.d_changed = nullptr;
 }
 
 // The cache entry of this raw call (g_raw_mutex held by the caller); entry->ctx is the context that serves it with the
@@ -662,6 +664,19 @@ RawEntry* raw_lookup(unsigned n, unsigned division, bool inverse, const u64* d_t
 hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d_tab, unsigned num, unsigned division, const ModSet& m,
                    hipStream_t s)
 {
+    // The comparison kernel of an earlier call found the table changed (host-mapped word, read without a synchronisation: a call or two
+    // late at worst): derive a new context from what the table holds now, instead of sending every later call through the guarded
+    // literal leg.  Launches on the old context may be in flight on any stream, hence the device-wide wait; an entry whose table has
+    // changed three times keeps the literal kernels (a buffer the caller rewrites for every call).
+    if (e && e->ctx && e->h_changed && *e->h_changed) {
+        (void)hipDeviceSynchronize();
+        *e->h_changed = 0;
+        mi355ntt_ctx_destroy(e->ctx);
+        e->ctx = ++e->rederived > 2 ? nullptr : raw_derive(e->device, e->n, e->division, e->inverse, e->tab, e->q, e->mu, e->bits);
+        (void)hipGetLastError();
+        e->used = false;
+        e->trusted = false;
+    }
     const mi355ntt_ctx* c = e ? e->ctx : nullptr;
     if (!c || c->literal_stages || (c->split16 && !e->trusted))
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
@@ -674,41 +689,42 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
-    if (!e->ev && (err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming)) != hipSuccess) return err;
-    if (e->used && e->last_stream != s && (err = hipStreamWaitEvent(s, e->ev, 0)) != hipSuccess) return err;
-    unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);
-    // n = 2^15, a batch the persistent kernels run: the transform's own workgroups compare the tables (checked_entry,
-    // kernels_fast_impl.cuh) -- one launch and no dependent read in front of the transform.  Its workgroups wait for each other, so
-    // the launch takes the device's pair-flag slot; when the slot is not to be had (another stream's waiting kernel in flight, a
-    // stream restricted to part of the CUs) the call keeps the comparison kernel in front.
-    bool done = false;
-    if (c->in_kernel_check && fast_in_kernel_check_ok(c->fast, num, division)) {
-        hipError_t st = hipSuccess;
-        if (PairSlot* slot = pair_acquire(s, &st)) {
-            err = inverse ? run_inverse(c, d_a, num, division, kGuardBit | kCheckInKernelBit, s) : run_forward(c, d_a, num, division, kGuardBit | kCheckInKernelBit, s);
-            pair_release(slot, s);
-            if (err != hipSuccess) return err;
-            done = true;
-        } else if (st != hipSuccess) {
-            // an earlier waiting kernel on this device gave up (reported here, nothing launched).  A checked launch that was in flight
-            // then may have left its arrival words behind: every cached entry's are zeroed in stream order before the error goes out
-            for (RawEntry& o : g_raw_cache)
-                if (o.ctx && o.ctx->in_kernel_check)
-                    (void)hipMemsetAsync(static_cast<char*>(o.ctx->fast.d_primes_alloc) + 32, 0, 12, s);      // GuardRec::arrive, depart, differ
-            return st;
+    // The guard words belong to the stream that used them last.  A call on another stream is ordered behind everything that stream has
+    // enqueued -- an event recorded on it NOW (round 6; until round 5 every call recorded one behind itself, a barrier packet and 6 us
+    // of idle GPU per call in the kernel trace: profiles/r06_raw_checked_calls.txt).  A stream that has been destroyed or is
+    // capturing by now cannot hand over: the call then runs the literal kernels with the caller's table, which share nothing.
+    if (e->used && e->last_stream != s) {
+        hipStreamCaptureStatus lcap = hipStreamCaptureStatusNone;
+        bool handed = hipStreamIsCapturing(e->last_stream, &lcap) == hipSuccess && lcap == hipStreamCaptureStatusNone;
+        if (handed && !e->ev) handed = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) == hipSuccess;
+        handed = handed && hipEventRecord(e->ev, e->last_stream) == hipSuccess && hipStreamWaitEvent(s, e->ev, 0) == hipSuccess;
+        if (!handed) {
+            (void)hipGetLastError();
+            return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
         }
     }
-    if (!done) {
-        if (++e->epoch == 0 || e->epoch >= 0xfffffff0u) e->epoch = 1;
-        if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s)) != hipSuccess) return err;
-        err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
-        if (err != hipSuccess) return err;
+    if (!e->h_changed) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            std::memset(h, 0, 64);
+            e->h_changed = static_cast<volatile unsigned*>(h);
+            e->d_changed = static_cast<unsigned*>(d);
+        } else {
+            if (h) (void)hipHostFree(h);
+            (void)hipGetLastError();
+        }
     }
+    unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);
+    if (++e->epoch == 0) e->epoch = 1;
+    if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s, e->d_changed)) != hipSuccess) return err;
+    err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
+    if (err != hipSuccess) return err;
     err = inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s, guard) : compat_forward_batch(d_a, n, d_tab, num, division, m, s, guard);
     if (err != hipSuccess) return err;
     e->used = true;
     e->last_stream = s;
-    return hipEventRecord(e->ev, s);
+    return hipSuccess;
 }
 
 }  // namespace

@@ -40,8 +40,6 @@ struct ModSet {
 // kGuardBit set in prime_base return at once when g[0] == g[1] (this call's table is not the cached one), the literal
 // kernels launched with a guard pointer return at once when g[0] != g[1] -- exactly one of the two transforms the data.
 constexpr unsigned kGuardBit = 0x80000000u;
-// with kGuardBit, n = 2^15 persistent kernels only (round 6): the launch compares the tables itself (kernels_fast_impl.cuh, checked_entry)
-constexpr unsigned kCheckInKernelBit = 0x40000000u;
 // fused products: OR-ed into `division`, the second operand holds `division` polynomials shared by the whole batch
 // (polynomial y multiplies with bhat[y % division]) -- the batched BFV drivers multiply every ciphertext with the same key
 constexpr unsigned kSharedB = 0x80000000u;
@@ -77,7 +75,9 @@ hipError_t compat_synth_splitmix(u64* d_a, unsigned n, unsigned num, unsigned di
 // *d_flag |= 1 when two sets of `count` reference-format tables differ in an entry the transforms read (index != 0)
 hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_flag, hipStream_t s);
 // the same as a stream-ordered check: guard[0] = epoch, and guard[1] = epoch when the tables differ
-hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s);
+// (d_host_word: device address of a host-mapped word that is set to 1 when they differ, or null)
+hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s,
+                               unsigned* d_host_word = nullptr);
 
 // ---- throughput kernels (kernels_fast.hip) ----
 // Device tables private to the fast path.  Built once per context from the reference-format tables.
@@ -113,12 +113,6 @@ hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, uns
 hipError_t fast_inverse_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s,
                                 const u64* d_bhat = nullptr);
 void fast_tables_destroy(FastTables* t);
-// Checked raw calls with the table comparison inside the throughput launch (kernels_fast_impl.cuh, checked_entry):
-// fast_guard_setup fills the context's guard record once (the raw-cache entry's table, the context's table of the same direction,
-// `division` tables of n words); fast_in_kernel_check_ok: a transform of `num` polynomials on this context is launches of n = 2^15
-// persistent kernels only (those that carry the comparison).
-hipError_t fast_guard_setup(const FastTables& t, const u64* caller_tab, const u64* ctx_tab, unsigned division);
-bool fast_in_kernel_check_ok(const FastTables& t, unsigned num, unsigned division);
 // measurement helper: a stream-ordered clock probe (20 us) and the shader clock it measured (the read synchronises)
 hipError_t fast_clock_probe(const FastTables& t, hipStream_t s);
 hipError_t fast_probed_clock_mhz(const FastTables& t, double* mhz);
@@ -144,7 +138,6 @@ hipError_t pair_init_current_device();                  // allocates the current
 PairSlot* pair_acquire(hipStream_t s, hipError_t* status = nullptr);
 void pair_release(PairSlot* slot, hipStream_t s);
 unsigned* pair_flags(PairSlot* slot);
-unsigned* pair_flags_current_device();                  // the current device's flag buffer (allocated on first use), null on failure
 // Watchdog of the spinning workgroups, in ticks of the 100 MHz constant clock (s_memrealtime): a partner that has not become resident
 // after this long means another tenant holds the CUs indefinitely.  The workgroup then GIVES UP instead of hanging (or trapping, which
 // would take the process's device context with it): it sets the last word of the flag buffer -- a workgroup of this or of a later

@@ -120,7 +120,8 @@ __global__ void __launch_bounds__(kBlock) tables_differ_kernel(const u64* __rest
 
 // Stream-ordered form of the same comparison (checked raw calls): guard[0] <- epoch; guard[1] <- epoch where they differ.
 __global__ void __launch_bounds__(kBlock) tables_check_kernel(const u64* __restrict__ x, const u64* __restrict__ y, unsigned n,
-                                                              unsigned count, unsigned* __restrict__ guard, unsigned epoch)
+                                                              unsigned count, unsigned* __restrict__ guard, unsigned epoch,
+                                                              unsigned* __restrict__ host_word)
 {
     bool diff = false;
     const ulonglong2* x2 = reinterpret_cast<const ulonglong2*>(x);
@@ -130,7 +131,12 @@ __global__ void __launch_bounds__(kBlock) tables_check_kernel(const u64* __restr
         const ulonglong2 u = x2[i], v = y2[i];
         if (u.y != v.y || (u.x != v.x && ((2 * i) & (n - 1)) != 0)) diff = true;      // entry 0 of a table is never read
     }
-    if (diff) guard[1] = epoch;          // (every writer stores the same value; a plain store stays right when the host epoch wraps)
+    if (diff) {
+        guard[1] = epoch;                // (every writer stores the same value; a plain store stays right when the host epoch wraps)
+        // host-mapped word of the raw-cache entry: its next call learns that the table no longer holds what the context was derived
+        // from and derives a new one (capi.cpp, raw_run) instead of taking the guarded literal leg for ever
+        if (host_word) __hip_atomic_store(host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) guard[0] = epoch;
 }
 
@@ -216,9 +222,10 @@ void launch_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsi
     const unsigned bpp = (n / 2 + kBlock - 1) / kBlock, sh = log2u(bpp);
     const unsigned long long total = (unsigned long long)num << sh;
     const unsigned blocks = total > 0xffffffffull ? 0xffffffffu : (unsigned)total;
-    // capped: a guarded launch that has nothing to do must cost ~nothing (its price is the dispatch of its workgroups: 1024 of them
-    // when the launch is a fallback leg that normally returns at once, 8192 when it is the transform)
-    const unsigned cap = guard ? 1024u : 8192u;
+    // capped: a guarded launch that has nothing to do must cost ~nothing (its price is the dispatch of its workgroups: 64 of them when
+    // the launch is a fallback leg that normally returns at once -- round 6: the raw-cache entry whose table has changed derives a new
+    // context at its next call, so the leg does real work once or twice per rewritten table, not for ever -- 8192 when it is the transform)
+    const unsigned cap = guard ? 64u : 8192u;
     const unsigned grid = blocks < cap ? blocks : cap;
     if (FWD) ct_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, sh, blocks, m, guard);
     else gs_stage_kernel<<<grid, kBlock, 0, s>>>(d_a, d_tabs, n, length, division, sh, blocks, m, guard);
@@ -228,8 +235,8 @@ void launch_stage(u64* d_a, unsigned n, const u64* d_tabs, unsigned length, unsi
 unsigned lds_grid(unsigned slices, int logs, bool guarded = false)
 {
     const unsigned per_cu = 163840u / (8u << logs) ? 163840u / (8u << logs) : 1u;
-    // 1024-thread workgroups: at most two per CU (one for a guarded fallback leg: it normally returns at once, see launch_stage)
-    const unsigned cap = current_device_cus() * (guarded ? 1u : per_cu > 2 ? 2 : per_cu);
+    // 1024-thread workgroups: at most two per CU (32 in all for a guarded fallback leg: it normally returns at once, see launch_stage)
+    const unsigned cap = guarded ? 32u : current_device_cus() * (per_cu > 2 ? 2 : per_cu);
     return slices < cap ? slices : cap;
 }
 
@@ -351,9 +358,10 @@ hipError_t compat_tables_differ(const u64* d_x, const u64* d_y, unsigned n, unsi
     return hipGetLastError();
 }
 
-hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s)
+hipError_t compat_tables_check(const u64* d_x, const u64* d_y, unsigned n, unsigned count, unsigned* d_guard, unsigned epoch, hipStream_t s,
+                               unsigned* d_host_word)
 {
-    tables_check_kernel<<<128, kBlock, 0, s>>>(d_x, d_y, n, count, d_guard, epoch);
+    tables_check_kernel<<<128, kBlock, 0, s>>>(d_x, d_y, n, count, d_guard, epoch, d_host_word);
     return hipGetLastError();
 }
 

@@ -9,7 +9,6 @@
 #include "ntt_core.cuh"
 #include "kernels_fast_impl.cuh"
 
-#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -221,13 +220,6 @@ void pair_release(PairSlot* p, hipStream_t s)
     g_pair_mutex.unlock();
 }
 unsigned* pair_flags(PairSlot* p) { return p->d_flags; }
-unsigned* pair_flags_current_device()
-{
-    int dev = 0;
-    if (pair_init_current_device() != hipSuccess || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    std::lock_guard<std::mutex> lock(g_pair_mutex);
-    return g_pair[dev].d_flags;
-}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -351,34 +343,6 @@ void fast_tables_destroy(FastTables* t)
     t->d_primes_alloc = nullptr;
     t->d_fwd = t->d_inv = nullptr;
     t->d_primes = nullptr;
-}
-
-hipError_t fast_guard_setup(const FastTables& t, const u64* caller_tab, const u64* ctx_tab, unsigned division)
-{
-    if (!t.d_primes_alloc) return hipErrorInvalidValue;
-    GuardRec g;
-    std::memset(&g, 0, sizeof(g));
-    g.nmask = t.n - 1u;
-    g.caller_tab = reinterpret_cast<const ulonglong2*>(caller_tab);
-    g.ctx_tab = reinterpret_cast<const ulonglong2*>(ctx_tab);
-    g.units = (unsigned long long)division * t.n / 2;
-    g.flags = pair_flags_current_device();
-    if (!g.flags) return hipErrorNotReady;
-    // (bytes 32 .. of the record: the guard words and the clock probe in front stay as they are)
-    return hipMemcpy(static_cast<char*>(t.d_primes_alloc) + offsetof(GuardRec, arrive), reinterpret_cast<const char*>(&g) + offsetof(GuardRec, arrive),
-                     sizeof(GuardRec) - offsetof(GuardRec, arrive), hipMemcpyHostToDevice);
-}
-
-static unsigned tail_split_head(const FastTables& t, unsigned num, unsigned division, bool fused);
-bool fast_in_kernel_check_ok(const FastTables& t, unsigned num, unsigned division)
-{
-    if (t.log_n != 15 || num == 0) return false;
-    static const bool off = std::getenv("MI355NTT_NO_IN_KERNEL_CHECK") != nullptr;      // (A/B measurements)
-    if (off) return false;
-    if ((t.hl & 15) == HL_LIT) return true;              // (class 0: persistent kernels at every batch size, tails included)
-    if (!in_kernel_check_class_rt(t.hl)) return false;   // (general-prime classes 4 and 6: no instantiation with the comparison inside)
-    if (tail_split_head(t, num, division, false)) return false;      // (the tail runs the small-batch kernels)
-    return !use_latency_path<15>(num, false);
 }
 
 hipError_t fast_clock_probe(const FastTables& t, hipStream_t s)

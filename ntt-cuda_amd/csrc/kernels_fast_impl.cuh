@@ -9,95 +9,6 @@
 
 namespace mi355ntt {
 
-// ---- checked raw calls: the table comparison INSIDE the throughput launch (round 6; n = 2^15 persistent kernels) ----------------
-// forwardNTT_batch / inverseNTT_batch hand over the caller's table on every call (ntt_60bit.cuh:608,652); the library serves them from
-// a context derived once per (table address, moduli), so each call has to establish that the table still holds what it held then.
-// Until round 5: a comparison kernel in front of every transform (4.4 us + a launch boundary), 6 % of the bench workload.  Now the
-// transform's own workgroups compare -- each its 1/grid share of the two tables (8 KiB at 4 primes and 256 workgroups), before they
-// load a single coefficient -- and agree through two words of the context's guard record: `arrive` counts workgroups that have
-// compared (low half) and those that found a difference (high half), `depart` counts workgroups that have read the verdict; the last
-// one to depart resets both and publishes the verdict for the guarded literal leg behind the launch (g0 == g1: the tables
-// differ, that leg transforms the data; the throughput workgroups return without a store).  The transform is in place, so nobody may
-// store before EVERYBODY has compared: a grid-wide wait.  The grid is persistent (one workgroup per CU), and the launch owns the
-// device's pair-flag slot like the other kernels whose workgroups wait for each other (pair_acquire, kernels.hpp: one such kernel
-// in flight per device, not under capture, every CU available to the stream) -- otherwise the call takes the three-launch form.
-// A workgroup that waits longer than the pair watchdog gives up exactly like a pair workgroup (pair_watchdog_check).
-// The comparison lives in instantiations of its own (template argument CHECKED): inlined into the kernels every call runs, its few
-// registers re-rolled the register allocation of the whole polynomial loop (tools/codeobj_digest.py: every n = 2^15 kernel changed,
-// k_inverse15<4 | 6, false> gained 12-44 bytes of scratch), and a real function call costs a stack.  The two general-prime classes
-// that spill with it (kernels_fast.hip, fast_in_kernel_check_ok) keep the comparison kernel in front.
-struct GuardRec {                           // the record in front of a context's PrimeDev array (sizeof(PrimeDev) bytes, zeroed at creation)
-    unsigned g0, g1, r2, r3;                // bytes 0..15: guard words of the literal leg (it runs iff g0 == g1)
-    unsigned long long probe[2];            // bytes 16..31: k_clock_probe
-    unsigned arrive, depart, differ, nmask; // bytes 32..47: nmask = n - 1
-    const ulonglong2* caller_tab;           // the table of the raw-cache entry this context serves ...
-    const ulonglong2* ctx_tab;              // ... and the context's own reference-format table of the same direction
-    unsigned long long units;               // 16-byte units to compare: division * n / 2
-    unsigned* flags;                        // the device's pair-flag buffer (dead mark, watchdog length, error word)
-};
-static_assert(sizeof(GuardRec) <= sizeof(PrimeDev), "the guard record is one PrimeDev slot");
-constexpr unsigned kCheckInKernel = kCheckInKernelBit;      // with kGuardBit in prime_base: compare here instead of reading a verdict
-constexpr unsigned kVerdictSame = 0xfffffffeu, kVerdictMark = 0xffffffffu;     // g0 = mark; g1 = mark (differ) or same
-
-// true: this launch must not touch the data.  `scratch`: one LDS word (the kernel's image, idle at this point).
-__device__ __forceinline__ bool checked_entry(const PrimeDev* primes, unsigned& prime_base, u64* scratch)
-{
-    if (!(prime_base & kGuardBit)) return false;
-    const bool in_kernel = (prime_base & kCheckInKernel) != 0;
-    prime_base &= ~(kGuardBit | kCheckInKernel);
-    GuardRec* g = const_cast<GuardRec*>(reinterpret_cast<const GuardRec*>(primes - 1));
-    if (!in_kernel) return g->g0 == g->g1;            // (the comparison kernel in front of this launch has left its verdict)
-    bool diff = false;
-    {
-        const ulonglong2* x = g->caller_tab;
-        const ulonglong2* y = g->ctx_tab;
-        const unsigned long long units = g->units, stride = (unsigned long long)gridDim.x * blockDim.x;
-        const unsigned nmask = g->nmask;
-        for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += stride) {
-            const ulonglong2 u = x[i], v = y[i];
-            if (u.y != v.y || (u.x != v.x && ((2 * i) & nmask) != 0)) diff = true;      // entry 0 of a table is never read
-        }
-    }
-    // (LDS word: any wave that saw a difference raises it; the image is idle at this point)
-    unsigned* word = reinterpret_cast<unsigned*>(scratch);
-    if (threadIdx.x == 0) *word = 0u;
-    __syncthreads();
-    if (__ballot(diff) != 0 && (threadIdx.x & 63u) == 0) atomicOr(word, 1u);
-    __syncthreads();                                  // every wave of this workgroup has compared
-    if (threadIdx.x == 0) {
-        // ONE relaxed atomic carries both facts -- low half: workgroups that have compared, high half: those that found a difference --
-        // so no ordering between two words is needed, and nothing is released or acquired: the tables were written before the launch,
-        // no data travels with the count.  (Release / acquire at agent scope write back and invalidate the XCD's L2 on this chip:
-        // measured, the first version of this protocol cost 42 us per launch that way -- 2.49 M against 2.96 M pairs/s.)
-        const unsigned mine = 1u + (*word ? 0x10000u : 0u);
-        *word = 1u;                                   // (a wave that gives up below ends: the rest of the workgroup then finds "do not store")
-        unsigned seen = __hip_atomic_fetch_add(&g->arrive, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
-        if ((seen & 0xffffu) < gridDim.x) {
-            const u64 fb = reinterpret_cast<u64>(g->flags);      // (wave-uniform; pinned in SGPRs: the watchdog reads through scalar loads)
-            unsigned* const flags = reinterpret_cast<unsigned*>(((u64)__builtin_amdgcn_readfirstlane(hi32(fb)) << 32) | __builtin_amdgcn_readfirstlane(lo32(fb)));
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (((seen = __hip_atomic_load(&g->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < gridDim.x) {
-                __builtin_amdgcn_s_sleep(2);
-                pair_watchdog_check(flags, t0);       // (ends the wave when the launch is dead or the watchdog has expired)
-            }
-        }
-        const unsigned d = seen >> 16;
-        if (__hip_atomic_fetch_add(&g->depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-            // everybody has read the verdict: publish it for the literal leg behind this launch (the kernel boundary makes it visible)
-            // and leave the words as they were found
-            __hip_atomic_store(&g->g0, kVerdictMark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&g->g1, d ? kVerdictMark : kVerdictSame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&g->depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&g->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *word = d;
-    }
-    __syncthreads();
-    const unsigned verdict = *word;
-    __syncthreads();                                  // (the word is the kernel's LDS image again from here on)
-    return verdict != 0;
-}
-
 // coalesced layout B0: register r of thread t holds coefficient (r << B0) | t; lane offset in a VGPR,
 // the r * (n/32) * 8 byte displacement in the buffer instruction's scalar offset
 // PAIR16: issue order (0, 16, 1, 17, ...) -- the order in which a forward round on register bits 4..0 consumes the
@@ -275,21 +186,15 @@ __device__ __forceinline__ void split_partner_read(u64 (&V)[8], const u64* slice
 // U - T (canonical: the upper half's input) in place over V and keeps U + T in registers as its own input (in [0, 2q): every
 // class's bound tracking admits that, see fwd_reduce_mask); the upper half is then an ordinary transform of what the same threads
 // stored.  Reads 1.5 x, writes 1.5 x the polynomial in ONE launch instead of 2 x / 2 x in two (a stage kernel in front).
-template <int HL, bool NEAR, int SPLIT = 0, bool CHECKED = false>
+template <int HL, bool NEAR, int SPLIT = 0>
 __global__ void __launch_bounds__(1024, 4)
 k_forward15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
             unsigned prime_base, unsigned num)
 {
-    static_assert(!CHECKED || SPLIT == 0, "the comparison rides in the plain n = 2^15 launch only");
-    if constexpr (!CHECKED) {
-        if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
-    }
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    if constexpr (CHECKED) {
-        if (checked_entry(primes, prime_base, lds)) return;   // ... established by this launch's own workgroups
-    }
     // Thread-derived values are rebuilt where they are used -- the wave index lives in an SGPR, the lane index comes from
     // v_mbcnt -- instead of surviving the polynomial loop in VGPRs the kernel does not have (they were its spills, reloaded
     // from scratch in front of the exchange and of the row store).
@@ -521,20 +426,15 @@ k_forward15_pair(u64* __restrict__ a, const TwPair* __restrict__ tw, const Prime
     if (threadIdx.x == 0) __hip_atomic_store(flag_at(1u - role), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero between launches
 }
 
-template <int HL, bool NEAR, bool CHECKED = false>
+template <int HL, bool NEAR>
 __global__ void __launch_bounds__(1024, 4)
 k_inverse15(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
             unsigned prime_base, unsigned num)
 {
-    if constexpr (!CHECKED) {
-        if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
-    }
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     constexpr int LOGN = 15;
     using G = Geo<LOGN>;
     __shared__ __attribute__((aligned(16))) u64 lds[G::LDS_WORDS];
-    if constexpr (CHECKED) {
-        if (checked_entry(primes, prime_base, lds)) return;   // ... established by this launch's own workgroups (checked_entry)
-    }
     const bool stream_loads = (division & kStreamLoads) != 0;        // (wave-uniform: a kernel argument)
     division &= ~kStreamLoads;
     // thread-derived values are rebuilt where they are used (wave index in an SGPR, lane index from v_mbcnt), as in
@@ -953,16 +853,6 @@ inline unsigned lit_grid(unsigned num, unsigned division)
     return g;
 }
 
-// classes whose n = 2^15 kernels exist with the table comparison inside (CHECKED): all but the general-prime classes 4 and 6, whose
-// inverse kernels leave the register file with it (12 / 44 bytes of scratch per lane)
-template <int H, bool NR>
-constexpr bool in_kernel_check_class() { return NR || (H != 4 && H != 6); }
-inline bool in_kernel_check_class_rt(int hl)
-{
-    const int h = hl & 15;
-    return h == HL_LIT || (hl & 16) != 0 || !(h >= 4);      // (dispatch_class: general primes run classes 6, 4, 3, 2)
-}
-
 template <int LOGN>
 hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                       hipStream_t s)
@@ -987,18 +877,8 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     dispatch_class(hl, [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
-        if constexpr (LOGN == 15) {
-            // (kCheckInKernelBit: the instantiation that compares the caller's table itself; never set for the two classes without one)
-            if constexpr (in_kernel_check_class<H, NR>()) {
-                if (base & kCheckInKernelBit) {
-                    k_forward15<H, NR, 0, true><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-                    return;
-                }
-            }
-            k_forward15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        } else {
-            k_forward<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        }
+        if constexpr (LOGN == 15) k_forward15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
+        else k_forward<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     });
     return hipGetLastError();
 }
@@ -1027,17 +907,8 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     dispatch_class(hl, [&](auto hc, auto nc) {
         constexpr int H = decltype(hc)::value;
         constexpr bool NR = decltype(nc)::value;
-        if constexpr (LOGN == 15) {
-            if constexpr (in_kernel_check_class<H, NR>()) {
-                if (base & kCheckInKernelBit) {
-                    k_inverse15<H, NR, true><<<g, b, 0, s>>>(d_a, tw, pr, inv15_division_word(division, num), base, num);
-                    return;
-                }
-            }
-            k_inverse15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, inv15_division_word(division, num), base, num);
-        } else {
-            k_inverse<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
-        }
+        if constexpr (LOGN == 15) k_inverse15<H, NR><<<g, b, 0, s>>>(d_a, tw, pr, inv15_division_word(division, num), base, num);
+        else k_inverse<LOGN, H, NR><<<g, b, 0, s>>>(d_a, tw, pr, division, base, num);
     });
     return hipGetLastError();
 }

@@ -97,9 +97,9 @@ __global__ void __launch_bounds__(1024, 4)
 k_forward15_lit(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
                 unsigned prime_base, unsigned num)
 {
+    if (guard_says_skip(primes, prime_base)) return;      // checked raw call whose table is not the cached one
     static_assert(LOGN == 15, "n = 2^15 only");
     __shared__ __attribute__((aligned(16))) u64 lds[Geo<15>::LDS_WORDS];
-    if (checked_entry(primes, prime_base, lds)) return;      // checked raw call whose table is not the cached one
     unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile("" : "+s"(wave_s));
     const unsigned mask = lit_mask_of(primes, prime_base, division);
@@ -148,9 +148,9 @@ __global__ void __launch_bounds__(1024, 4)
 k_inverse15_lit(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division,
                 unsigned prime_base, unsigned num)
 {
+    if (guard_says_skip(primes, prime_base)) return;
     static_assert(LOGN == 15, "n = 2^15 only");
     __shared__ __attribute__((aligned(16))) u64 lds[Geo<15>::LDS_WORDS];
-    if (checked_entry(primes, prime_base, lds)) return;      // checked raw call whose table is not the cached one
     unsigned wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile("" : "+s"(wave_s));
     const unsigned mask = lit_mask_of(primes, prime_base, division);

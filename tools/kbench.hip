@@ -1,7 +1,7 @@
 // kbench.hip -- standalone timing of the n = 2^15 single-pass kernels, launched directly (no library, no context): the lazy class
 // <4, near-2^k> the headline runs (k_forward15 / k_inverse15) and the literal class 0 (k_forward15_lit / k_inverse15_lit).
 //   tools/build_kbench.sh <tag> [-DMI355NTT_TUNE_HEADER='"my_tune.hpp"']      -> tools/kbench_<tag>
-//   tools/kbench_<tag> [polynomials = 1024] [samples = 20] [kind: 0 lazy, 1 literal, 2 lazy with the table comparison inside] [warm launches = 3]
+//   tools/kbench_<tag> [polynomials = 1024] [samples = 20] [kind: 0 lazy, 1 literal] [warm launches = 3]
 // KB_B2B=L: each sample times L back-to-back launches; KB_PAIR=1: also forward -> inverse pairs over the same buffer.
 // The kernels carry no experiment switches any more (round 6): a variant build substitutes csrc/tune.hpp's struct through
 // MI355NTT_TUNE_HEADER; the ablation / stamp builds of rounds 1-5 are reproducible from commit 3b06c3b.
@@ -27,8 +27,7 @@ int main(int argc, char** argv)
     const int kind = argc > 3 ? atoi(argv[3]) : 0;
     const int warm = argc > 4 ? atoi(argv[4]) : 3;
     // lazy: BASELINE's first 60-bit prime; literal: a Barrett-inexact 60-bit prime (tests/params.py INEXACT_PRIMES[60])
-    const bool lit = kind == 1, checked = kind == 2;
-    const u64 q = lit ? 1137833256315125761ULL : 1152921504606584833ULL, psi = lit ? 448230823712243253ULL : 4443670208963ULL;
+    const u64 q = kind ? 1137833256315125761ULL : 1152921504606584833ULL, psi = kind ? 448230823712243253ULL : 4443670208963ULL;
     PrimeParams pp;
     if (derive_prime(n, q, psi, &pp)) { printf("bad prime\n"); return 1; }
     std::vector<u64> tab(n);
@@ -39,8 +38,8 @@ int main(int argc, char** argv)
     d.q = q; d.nq = 0ULL - q;
     d.mu = pp.mu; d.k = pp.k; d.red_sh1 = pp.k - 17; d.red_sh2 = 16; d.red_c = (u32)((((u128)1) << (31 + pp.k)) / q);
     for (int j = 0; j < 32; j++) d.twn[j] = TwPair{tab[j] % q, shoup(tab[j] % q, q)};
-    d.delta = lit ? 0u : (u32)((1ull << pp.k) - q); d.near_sh = pp.k - 32; d.near_mask = (u32)((1ull << (pp.k - 32)) - 1);
-    d.lit = lit ? 1u : 0u;
+    d.delta = kind ? 0u : (u32)((1ull << pp.k) - q); d.near_sh = pp.k - 32; d.near_mask = (u32)((1ull << (pp.k - 32)) - 1);
+    d.lit = kind ? 1u : 0u;
     u64* a; TwPair* dtw; PrimeDev* dp;
     CK(hipMalloc(&a, (size_t)num * n * 8));
     CK(hipMalloc(&dtw, n * sizeof(TwPair)));
@@ -53,27 +52,13 @@ int main(int argc, char** argv)
     CK(hipMemcpy(a, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtw, tw.data(), n * sizeof(TwPair), hipMemcpyHostToDevice));
     CK(hipMemcpy(dp, &d, sizeof(d), hipMemcpyHostToDevice));
-    unsigned base = 0;
-    if (checked) {       // the guard record of a checked raw call: both table pointers at the same reference-format table (they agree)
-        u64* dtab; unsigned* dflags;
-        CK(hipMalloc(&dtab, n * 8)); CK(hipMemcpy(dtab, tab.data(), n * 8, hipMemcpyHostToDevice));
-        CK(hipMalloc(&dflags, kPairFlagWords * 4)); CK(hipMemset(dflags, 0, kPairFlagWords * 4));
-        const unsigned long long tail[2] = {kPairWatchdogTicks, 0ull};
-        CK(hipMemcpy(dflags + kPairTicksWord, tail, sizeof(tail), hipMemcpyHostToDevice));
-        GuardRec gr{};
-        gr.nmask = n - 1; gr.caller_tab = (const ulonglong2*)dtab; gr.ctx_tab = (const ulonglong2*)dtab; gr.units = n / 2; gr.flags = dflags;
-        CK(hipMemcpy(dp - 1, &gr, sizeof(gr), hipMemcpyHostToDevice));
-        base = kGuardBit | kCheckInKernelBit;
-    }
     const dim3 g(persistent_grid<LOGN>(num)), b(1024);
     auto fwd = [&]() {
-        if (lit) k_forward15_lit<LOGN><<<g, b>>>(a, dtw, dp, 1, 0, num);
-        else if (checked) k_forward15<4, true, 0, true><<<g, b>>>(a, dtw, dp, 1, base, num);
+        if (kind) k_forward15_lit<LOGN><<<g, b>>>(a, dtw, dp, 1, 0, num);
         else k_forward15<4, true><<<g, b>>>(a, dtw, dp, 1, 0, num);
     };
     auto inv = [&]() {
-        if (lit) k_inverse15_lit<LOGN><<<g, b>>>(a, dtw, dp, 1, 0, num);
-        else if (checked) k_inverse15<4, true, true><<<g, b>>>(a, dtw, dp, inv15_division_word(1, num), base, num);
+        if (kind) k_inverse15_lit<LOGN><<<g, b>>>(a, dtw, dp, 1, 0, num);
         else k_inverse15<4, true><<<g, b>>>(a, dtw, dp, inv15_division_word(1, num), 0, num);
     };
     hipEvent_t e0, e1;
@@ -101,7 +86,7 @@ int main(int argc, char** argv)
         std::sort(ts.begin(), ts.end());
         const double med = ts[ts.size() / 2];
         printf("%-16s %s  num %5u  median %.4f ms  min %.4f ms  -> %.3f M transforms/s, %.2f TB/s algorithmic\n", names[which],
-               lit ? "literal (class 0)" : checked ? "lazy, checked  " : "lazy <4, near>", num, med, ts[0], (which == 2 ? 2.0 : 1.0) * num / (med * 1e-3) / 1e6,
+               kind ? "literal (class 0)" : "lazy <4, near>", num, med, ts[0], (which == 2 ? 2.0 : 1.0) * num / (med * 1e-3) / 1e6,
                (which == 2 ? 2.0 : 1.0) * num * 524288.0 / (med * 1e-3) / 1e12);
     }
     CK(hipGetLastError());
