@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/mi355ntt.h"
 #include "hostparams.hpp"
 #include "kernels.hpp"
 
@@ -56,8 +57,18 @@ hipError_t bfv_sample_encrypt(const BfvParams& p, const BfvDevice& d, const unsi
 hipError_t bfv_add_negate(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* e, hipStream_t s);
 // pk0 (holding NTT(e)) <- -(a_hat (.) s_hat + pk0): the key generation's product, sum and negation in the NTT domain
 hipError_t bfv_keygen_pk0(const BfvParams& p, const BfvDevice& d, u64* pk0, const u64* a_hat, const u64* s_hat, hipStream_t s);
+// the fused product with the per-prime element-wise step in its store path (capi.cpp, kernels_epi.cuh): 0 done, 1 not available here
+// (the caller runs the two steps one after the other), < 0 an MI355NTT_E* code
+int ctx_polymul_epi(const mi355ntt_ctx* c, int kind, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, unsigned group,
+                    const u64* d_other, const void* d_consts, hipStream_t s);
+struct BfvEpiPrime {          // = EpiPrime (kernels_epi.cuh)
+    u64 k1, k2;
+    unsigned on, pad;
+};
+
 // poly_add_xq + divide_and_round_q_last_inplace_add_x2 + divide_and_round_q_last_inplace_loop_xq + weird_m_stuff
 // (bfv_encryption.cuh:110-208) on c [2][R][n], e [2][R][n], m [n]: one pass, same words as the four launches
+// (e == nullptr: the sum c + e has already been formed -- by the fused product's epilogue)
 hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s, unsigned count = 1);
 // poly_add_xq_d + poly_mul_int_xq_prodtgamma + poly_mul_int_xq_invpq (bfv_decryption.cuh:13-57) on c [2][R][n]
 hipError_t bfv_decrypt_scale(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count = 1);

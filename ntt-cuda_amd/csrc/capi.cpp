@@ -106,6 +106,24 @@ static hipError_t run_inverse(const mi355ntt_ctx* c, u64* d_a, unsigned num, uns
     return fast_inverse_batch(c->fast, d_a, num, division, base, s);
 }
 
+// The fused product with an element-wise epilogue for the batched BFV drivers (bfv_host.cpp; kernels_epi.cuh): MI355NTT_OK, a negative
+// error, or 1 = "not on this context / batch": the caller then runs the product and its element-wise kernel one after the other.
+namespace mi355ntt {
+int ctx_polymul_epi(const mi355ntt_ctx* c, int kind, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, unsigned group,
+                    const u64* d_other, const void* d_consts, hipStream_t s)
+{
+    if (!c || !d_a || !d_bhat || !d_other || !d_consts || division == 0 || division > c->num_primes) return MI355NTT_EINVAL;
+    if (c->literal || c->split16 || !fast_polymul_epi_ok(c->fast, num, division)) return 1;
+    const hipError_t e = fast_polymul_batch_epi(c->fast, kind, d_a, d_bhat, num, division, s, true, group, d_other, d_consts);
+    if (e == hipErrorNotSupported) return 1;
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return MI355NTT_EHIP;
+    }
+    return MI355NTT_OK;
+}
+}  // namespace mi355ntt
+
 static bool is_pow2(unsigned n) { return n && !(n & (n - 1)); }
 
 static int check_n(unsigned n)

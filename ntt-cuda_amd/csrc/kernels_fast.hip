@@ -467,6 +467,23 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
     return hipGetLastError();
 }
 
+bool fast_polymul_epi_ok(const FastTables& t, unsigned num, unsigned division)
+{
+    static const bool off = std::getenv("MI355NTT_NO_FUSED_EPILOGUE") != nullptr;      // (A/B measurements)
+    if (off || t.log_n != 15 || (t.hl & 15) == HL_LIT || num == 0) return false;
+    return !tail_split_head(t, num, division, true);     // (one persistent launch, or the three small-batch launches)
+}
+
+hipError_t fast_polymul_batch_epi(const FastTables& t, int kind, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
+                                  bool shared_b, unsigned group, const u64* d_other, const void* d_consts)
+{
+    if (!fast_polymul_epi_ok(t, num, division)) return hipErrorNotSupported;
+    if (shared_b && (division > kDivisionMask || group >= (kSharedB >> kSharedGroupShift) || (group && group % division))) return hipErrorInvalidValue;
+    if (shared_b) division |= kSharedB | (group << kSharedGroupShift);
+    return fast_mul_epi_15(kind, t.hl, d_a, d_bhat, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const TwPair*>(t.d_inv),
+                           reinterpret_cast<const PrimeDev*>(t.d_primes), num, division, s, d_other, d_consts);
+}
+
 hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
                               bool shared_b, unsigned group)
 {

@@ -956,6 +956,9 @@ MI355NTT_DECLARE_SIZE(12)
 MI355NTT_DECLARE_SIZE(13)
 MI355NTT_DECLARE_SIZE(14)
 MI355NTT_DECLARE_SIZE(15)
+// (kernels_fast_n15e.hip: the fused product with an epilogue, kernels_epi.cuh)
+hipError_t fast_mul_epi_15(int kind, int hl, u64* d_a, const u64* d_b, const TwPair* twf, const TwPair* twi, const PrimeDev* pr, unsigned num,
+                           unsigned division, hipStream_t s, const u64* other, const void* consts);
 bool fast_split_ok_16(unsigned num, int op, bool pair);   // (kernels_fast_n16.hip; op: 0 forward, 1 inverse, 2 fused product)
 hipError_t fast_fwd_pair_16(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, unsigned num, unsigned division, unsigned base,
                             hipStream_t s, unsigned* d_flags);      // (two workgroups per polynomial; d_flags: the device's pair-flag buffer, kernels.hpp)
