@@ -68,7 +68,6 @@ struct BfvEpiPrime {          // = EpiPrime (kernels_epi.cuh)
 
 // poly_add_xq + divide_and_round_q_last_inplace_add_x2 + divide_and_round_q_last_inplace_loop_xq + weird_m_stuff
 // (bfv_encryption.cuh:110-208) on c [2][R][n], e [2][R][n], m [n]: one pass, same words as the four launches
-// (e == nullptr: the sum c + e has already been formed -- by the fused product's epilogue)
 hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s, unsigned count = 1);
 // poly_add_xq_d + poly_mul_int_xq_prodtgamma + poly_mul_int_xq_invpq (bfv_decryption.cuh:13-57) on c [2][R][n]
 hipError_t bfv_decrypt_scale(const BfvParams& p, const BfvDevice& d, u64* c, hipStream_t s, unsigned count = 1);

@@ -96,7 +96,8 @@ struct mi355ntt_bfv {
     BfvDevice d;
     void* d_prime = nullptr;
     void* d_bcm = nullptr;
-    void* d_epi = nullptr;        // [2][R] BfvEpiPrime: the epilogue constants of the batched decryption ([0][i]) and encryption ([1][i])
+    void* d_epi = nullptr;        // [R] BfvEpiPrime: the epilogue constants of the batched decryption
+    bool epi_ok = false;          // the one-product form of the scaling is the reference's words for these moduli
 };
 
 #define BFV_HIP(expr)                         \
@@ -145,18 +146,22 @@ int mi355ntt_bfv_create(mi355ntt_bfv** out, unsigned n, unsigned num_primes, con
     b->d.d_prime = static_cast<const BfvPrime*>(b->d_prime);
     b->d.d_base_change = static_cast<const u64*>(b->d_bcm);
     {
-        // the element-wise steps the fused product's epilogue takes over in the batched drivers (kernels_epi.cuh): decryption scales the
-        // r primes of the ciphertext modulus and leaves the dropped prime's slot alone, encryption adds e on all R
-        BfvEpiPrime epi[2 * kMaxPrimes];
+        // the element-wise step the fused product's epilogue takes over in the batched decryption (kernels_epi.cuh): the r primes of
+        // the ciphertext modulus are scaled by k_i = (t gamma) q~_i^-1 mod q_i, the dropped prime's slot is left alone.  ONE exact
+        // product stands for the reference's two Barrett products only where those are exact -- for every operand the sum can be,
+        // q itself included (`>`): the bound of barrett_single_subtraction_exact with q (q - 1) in place of (q - 1)^2.
+        BfvEpiPrime epi[kMaxPrimes];
         std::memset(epi, 0, sizeof(epi));
+        b->epi_ok = true;
         for (unsigned i = 0; i < num_primes; i++) {
-            epi[i].k1 = b->p.prime[i].prod_t_gamma_mod_q;
-            epi[i].k2 = b->p.prime[i].inv_punctured_q;
+            const u64 qi = b->p.prime[i].q;
+            epi[i].k1 = mulmod(b->p.prime[i].prod_t_gamma_mod_q, b->p.prime[i].inv_punctured_q, qi);
+            epi[i].k2 = shoup(epi[i].k1, qi);
             epi[i].on = i < b->p.r ? 1u : 0u;
-            epi[num_primes + i].on = 1u;
+            if (i < b->p.r && !barrett_exact_for_operand_q(qi, b->p.prime[i].k, b->p.prime[i].mu)) b->epi_ok = false;
         }
-        if ((e = hipMalloc(&b->d_epi, sizeof(BfvEpiPrime) * 2 * num_primes)) != hipSuccess ||
-            (e = hipMemcpy(b->d_epi, epi, sizeof(BfvEpiPrime) * 2 * num_primes, hipMemcpyHostToDevice)) != hipSuccess) {
+        if ((e = hipMalloc(&b->d_epi, sizeof(BfvEpiPrime) * num_primes)) != hipSuccess ||
+            (e = hipMemcpy(b->d_epi, epi, sizeof(BfvEpiPrime) * num_primes, hipMemcpyHostToDevice)) != hipSuccess) {
             record_hip_error((int)e);
             mi355ntt_bfv_destroy(b);
             return e == hipErrorOutOfMemory ? MI355NTT_ENOMEM : MI355NTT_EHIP;
@@ -271,15 +276,7 @@ int mi355ntt_bfv_encrypt_batch(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const m
     const unsigned R = b->p.R;
     if (!bfv_batch_count_ok(count, R)) return MI355NTT_EUNSUPPORTED;      /* before anything touches d_c */
     BFV_ON_DEVICE(b);
-    /* :268-271 for the whole batch in one launch: the first count R polynomials with pk0, the rest with pk1 -- and, where the batch
-     * runs the persistent n = 2^15 kernel, poly_add_xq (:279) in its store path: the tail then reads c alone */
-    const int fused = ctx_polymul_epi(b->ntt, 2, d_c, d_public_key, 2 * count * R, R, count * R, d_e,
-                                      static_cast<const BfvEpiPrime*>(b->d_epi) + R, (hipStream_t)stream);
-    if (fused < 0) return fused;
-    if (fused == 0) {
-        BFV_HIP(bfv_encrypt_tail(b->p, b->d, d_c, nullptr, d_m, (hipStream_t)stream, count));                    /* :280-289 */
-        return MI355NTT_OK;
-    }
+    /* :268-271 for the whole batch in one launch: the first count R polynomials with pk0, the rest with pk1 */
     BFV_RC(mi355ntt_polymul_batch_shared(b->ntt, d_c, d_public_key, 2 * count * R, R, count * R, stream));
     BFV_HIP(bfv_encrypt_tail(b->p, b->d, d_c, d_e, d_m, (hipStream_t)stream, count));                            /* :278-289 */
     return MI355NTT_OK;
@@ -296,7 +293,7 @@ int mi355ntt_bfv_decrypt_batch(const mi355ntt_bfv* b, mi355ntt_u64* d_c, const m
     BFV_ON_DEVICE(b);
     /* bfv_decryption.cuh:98-101 on the c1 run of the batch; the slot of the dropped last prime is carried along unused.  Where the
      * batch runs the persistent n = 2^15 kernel the scaling (:103-121) rides in the product's store path */
-    const int fused = ctx_polymul_epi(b->ntt, 1, d_c + half, d_secret_key, count * R, R, 0, d_c, b->d_epi, (hipStream_t)stream);
+    const int fused = b->epi_ok ? ctx_polymul_epi(b->ntt, 1, d_c + half, d_secret_key, count * R, R, 0, d_c, b->d_epi, (hipStream_t)stream) : 1;
     if (fused < 0) return fused;
     if (fused != 0) {
         BFV_RC(mi355ntt_polymul_batch_shared(b->ntt, d_c + half, d_secret_key, count * R, R, 0, stream));

@@ -33,6 +33,18 @@ bool barrett_single_subtraction_exact(u64 q, unsigned k, u64 mu)
     return bound < 1.0L - 1e-9L;
 }
 
+// the same bound for products x y with x = q allowed (y < q): the sums the BFV drivers form with `>` instead of `>=` may equal q
+// (bfv_decryption.cuh:13-23), and a product by a constant then has to come out 0 for a one-product form to stand for it
+bool barrett_exact_for_operand_q(u64 q, unsigned k, u64 mu)
+{
+    if (k < 3 || k > 62 || q < 2) return false;
+    const u128 two2k = ((u128)1) << (2 * k);
+    const long double f = (long double)(u64)(two2k % q) / (long double)q;
+    const long double top = (long double)(q - 1) / ldexpl(1.0L, (int)k), topq = (long double)q / ldexpl(1.0L, (int)k);
+    const long double bound = topq * top * f + (long double)mu / ldexpl(1.0L, (int)k + 2);
+    return bound < 1.0L - 1e-9L;
+}
+
 u64 mulmod(u64 a, u64 b, u64 m) { return (u64)(((u128)a * b) % m); }
 
 // helper.h:8-28 (square-and-multiply, LSB first); reduced result for every exponent

@@ -22,6 +22,7 @@ void fill_table(u64 root, u64 q, unsigned n, u64* tab);
 // Does the reference's Barrett (Algorithm 7, ONE conditional subtraction: ntt_60bit.cuh:44-61) return the canonical
 // residue for every product of two canonical operands?  See hostparams.cpp.
 bool barrett_single_subtraction_exact(u64 q, unsigned k, u64 mu);
+bool barrett_exact_for_operand_q(u64 q, unsigned k, u64 mu);      // ... with one operand equal to q itself
 
 // Everything the device kernels need for one prime.
 struct PrimeParams {

@@ -95,9 +95,7 @@ k_keygen_pk0(u64* __restrict__ pk0, const u64* __restrict__ a_hat, const u64* __
 // +half on the last one (:110-124), subtract-and-scale on the others (:126-171), message term on c0 (:186-208).
 // The reference's two `%` (:150 last % q_j, :204 the message term) are reduce64 -- the same words for every input; its
 // `/ t` (:203) is 0 or 1 for a message below t and a real division otherwise.
-// ADD = false: the sums c + e (poly_add_xq) have already been formed by the fused product's epilogue (kernels_epi.cuh, EPI = 2);
-// e is not read.
-template <int V, bool ADD = true>
+template <int V>
 __global__ void __launch_bounds__(kBlock)
 k_encrypt_tail(u64* __restrict__ c, const u64* __restrict__ e, const u64* __restrict__ m, unsigned n, unsigned R, u64 t,
                const BfvPrime* __restrict__ primes, size_t half_stride)
@@ -110,15 +108,13 @@ k_encrypt_tail(u64* __restrict__ c, const u64* __restrict__ e, const u64* __rest
     const u64* eh = e + (size_t)blockIdx.z * R * n + h * half_stride;
     m += (size_t)blockIdx.z * n;
     const u64 q_last = primes[r].q, half_last = q_last >> 1;
-    u64 last[V], el[V] = {};
+    u64 last[V], el[V];
     ldv<V>(last, ch + (size_t)r * n + i);
-    if constexpr (ADD) ldv<V>(el, eh + (size_t)r * n + i);
+    ldv<V>(el, eh + (size_t)r * n + i);
 #pragma unroll
     for (int v = 0; v < V; v++) {
-        if constexpr (ADD) {
-            last[v] += el[v];
-            if (last[v] > q_last) last[v] -= q_last;           // poly_add_xq
-        }
+        last[v] += el[v];
+        if (last[v] > q_last) last[v] -= q_last;               // poly_add_xq
         last[v] += half_last;                                  // ..._add_x2
         if (last[v] >= q_last) last[v] -= q_last;
     }
@@ -134,15 +130,13 @@ k_encrypt_tail(u64* __restrict__ c, const u64* __restrict__ e, const u64* __rest
     }
     for (unsigned j = 0; j < r; j++) {
         const BfvPrime p = primes[j];
-        u64 x[V], ex[V] = {};
+        u64 x[V], ex[V];
         ldv<V>(x, ch + (size_t)j * n + i);
-        if constexpr (ADD) ldv<V>(ex, eh + (size_t)j * n + i);
+        ldv<V>(ex, eh + (size_t)j * n + i);
 #pragma unroll
         for (int v = 0; v < V; v++) {
-            if constexpr (ADD) {
-                x[v] += ex[v];
-                if (x[v] > p.q) x[v] -= p.q;                   // poly_add_xq
-            }
+            x[v] += ex[v];
+            if (x[v] > p.q) x[v] -= p.q;                       // poly_add_xq
             u64 tmp = reduce64(last[v], p.q, p.m64);           // ..._loop_xq
             if (tmp < p.half_last_mod_q) tmp += p.q;
             tmp -= p.half_last_mod_q;
@@ -362,11 +356,6 @@ hipError_t bfv_keygen_pk0(const BfvParams& p, const BfvDevice& d, u64* pk0, cons
 hipError_t bfv_encrypt_tail(const BfvParams& p, const BfvDevice& d, u64* c, const u64* e, const u64* m, hipStream_t s, unsigned count)
 {
     const size_t hs = (size_t)count * p.R * p.n;
-    if (!e) {
-        if (aligned16(c, m)) k_encrypt_tail<2, false><<<dim3(p.n / (2 * kBlock), 2, count), kBlock, 0, s>>>(c, c, m, p.n, p.R, p.t, d.d_prime, hs);
-        else k_encrypt_tail<1, false><<<dim3(p.n / kBlock, 2, count), kBlock, 0, s>>>(c, c, m, p.n, p.R, p.t, d.d_prime, hs);
-        return hipGetLastError();
-    }
     if (aligned16(c, e, m)) k_encrypt_tail<2><<<dim3(p.n / (2 * kBlock), 2, count), kBlock, 0, s>>>(c, e, m, p.n, p.R, p.t, d.d_prime, hs);
     else k_encrypt_tail<1><<<dim3(p.n / kBlock, 2, count), kBlock, 0, s>>>(c, e, m, p.n, p.R, p.t, d.d_prime, hs);
     return hipGetLastError();

@@ -1,10 +1,15 @@
 // kernels_epi.cuh -- the fused product of n = 2^15 with a per-prime element-wise EPILOGUE in its store path (round 6, VERDICT r05
 // item 4): the batched BFV drivers of configs[4] made element-wise passes over memory that need nothing but the polynomial the fused
 // product already holds in registers.
-//   EPI = 1 (decryption, bfv_decryption.cuh:98-122): c1 <- ((c1 s_hat + c0, `>`) (t gamma mod q)) (q~_i^-1 mod q) -- poly_add_xq_d,
-//           poly_mul_int_xq_prodtgamma, poly_mul_int_xq_invpq: the three launches k_decrypt_scale had already fused into one pass.
-//   EPI = 2 (encryption, bfv_encryption.cuh:279): c <- c pk + e (`>`): poly_add_xq; what follows crosses the primes (division by q_last)
-//           and stays in k_encrypt_tail.
+//   decryption (bfv_decryption.cuh:98-122): c1 <- ((c1 s_hat + c0, `>`) (t gamma mod q)) (q~_i^-1 mod q) -- poly_add_xq_d,
+//           poly_mul_int_xq_prodtgamma, poly_mul_int_xq_invpq: the three launches k_decrypt_scale had already fused into one pass.  Every
+//           modulus of a context that runs these kernels is Barrett-exact, so the two Barrett products by constants are ONE exact product
+//           by k = (t gamma) q~_i^-1 mod q_i -- a Shoup product with a precomputed companion, canonicalised: the same words for a third of
+//           the multiplies.  (The sum may equal q, `>`: the reference's products then return 0, as does this one; bfv_host.cpp checks the
+//           exactness bound for that operand as well before it hands the constants out.)
+//   (The encryption's `+ e` (bfv_encryption.cuh:279) was built the same way and measured: 378.7 against 364.7 us per 64 ciphertexts --
+//   the loads of e in front of a plain store cost the product more than k_encrypt_tail saves by not reading e.  Not shipped:
+//   profiles/r06_bfv_batch.txt.)
 // The second polynomial (c0 / e: the same position in a buffer of the same shape) arrives like the partner rows of the n = 2^16
 // kernels: LDS-direct loads into the wave's slice (split_partner_fetch: two 512-byte rows of layout 10 per instruction, no VGPRs),
 // sixteen rows requested right behind the workgroup-wide exchange -- they land during the last inverse round -- and the other sixteen
@@ -15,7 +20,7 @@
 namespace mi355ntt {
 
 struct EpiPrime {             // per prime of the call (index y % division); read by scalar loads
-    u64 k1, k2;               // EPI 1: (t gamma) mod q_i, q~_i^-1 mod q_i
+    u64 k1, k2;               // k = (t gamma) q~_i^-1 mod q_i and its Shoup companion floor(k 2^64 / q_i)
     unsigned on;              // 0: this polynomial is stored as the product leaves it (the dropped prime's slot of a decryption batch)
     unsigned pad;
 };
@@ -24,12 +29,18 @@ struct PolymulEpi {
     const EpiPrime* consts;
 };
 
+// x k mod q, canonical, for x <= q: the exact-quotient Shoup product (result in [0, 2q)) and one conditional subtraction
+__device__ __forceinline__ u64 epi_scale(u64 x, const EpiPrime& ec, const PrimeDev& p)
+{
+    return canon_2q(mul_shoup2(x, ec.k1, ec.k2, p.nq), p.q);
+}
+
 template <int HL, bool NEAR, int EPI>
 __global__ void __launch_bounds__(1024, 4)
 k_polymul15_epi(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
                 const PrimeDev* __restrict__ primes, unsigned division, unsigned num, PolymulEpi epi)
 {
-    static_assert(EPI == 1 || EPI == 2, "1: decryption scale, 2: encryption add");
+    static_assert(EPI == 1, "1: decryption scale");
     const bool stream_b = (division & (kSharedB | kStreamLoads)) == kStreamLoads;
     if (stream_b) division &= ~kStreamLoads;
     const SharedB sb(division);
@@ -118,11 +129,8 @@ k_polymul15_epi(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair*
                 static_for<8>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, r = 8 * c + i;
                     u64 ra = v[r] + O[i];
-                    if (ra > p.q) ra -= p.q;              // poly_add_xq / poly_add_xq_d: `>`, not `>=` (a sum equal to q stays q)
-                    if constexpr (EPI == 1) {
-                        ra = barrett_mul(ra, ec.k1, p.q, p.mu, p.k);
-                        ra = barrett_mul(ra, ec.k2, p.q, p.mu, p.k);
-                    }
+                    if (ra > p.q) ra -= p.q;              // poly_add_xq_d: `>`, not `>=` (a sum equal to q stays q)
+                    ra = epi_scale(ra, ec, p);
                     v2u32 x;
                     x.x = lo32(ra); x.y = hi32(ra);
                     __builtin_amdgcn_raw_buffer_store_b64(x, prs, voff, ((unsigned)r << G::B0) * 8u, Tune::kInv15AuxSt);
@@ -167,21 +175,18 @@ k_lat_inv_a_epi(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeD
         u64 ra = canon_after_inverse<HL, NEAR>(v[r], p);
         if (ec.on) {
             ra += o[r];
-            if (ra > p.q) ra -= p.q;                      // poly_add_xq / poly_add_xq_d: `>`
-            if constexpr (EPI == 1) {
-                ra = barrett_mul(ra, ec.k1, p.q, p.mu, p.k);
-                ra = barrett_mul(ra, ec.k2, p.q, p.mu, p.k);
-            }
+            if (ra > p.q) ra -= p.q;                      // poly_add_xq_d: `>`
+            ra = epi_scale(ra, ec, p);
         }
         buf_store_u64(prs, voff, ((r << (LOGN - 3)) | (k << (6 + L::GB))) * 8u, ra);
     });
 }
 
 // Classes whose kernel holds the epilogue without leaving the register file (compiler remarks, tools/kernel_resources.py): every
-// near-2^k class with 4q of headroom and the general class 6 -- plus, for the cheaper encryption epilogue, the general class 3.  The
-// exact-quotient classes (62-bit moduli) and the general class 4 take 8-48 bytes of scratch with it and keep the two separate steps.
+// near-2^k class with 4q of headroom and the general class 6.  The exact-quotient classes (62-bit moduli) and the general classes 4 and 3
+// take 8-48 bytes of scratch with it and keep the two separate steps.
 template <int H, bool NR, int EPI>
-constexpr bool epi_class() { return NR ? H >= 3 : (H == 6 || (EPI == 2 && H == 3)); }
+constexpr bool epi_class() { return NR ? H >= 3 : H == 6; }
 
 // the fused product of `num` polynomials with the epilogue, one persistent launch (the callers have asked fast_polymul_epi_ok)
 template <int EPI>
