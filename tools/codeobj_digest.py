@@ -90,6 +90,13 @@ def digests(path):
     return res
 
 
+def named_digests(path):
+    """{demangled kernel name: sha256 of its instruction stream} of one object / library"""
+    d = digests(path)
+    names = subprocess.run(["c++filt"], input="\n".join(d), capture_output=True, text=True).stdout.splitlines()
+    return {re.sub(r"\(.*", "", nm).replace("void ", "").replace("mi355ntt::", ""): h for (raw, (h, n)), nm in zip(d.items(), names)}
+
+
 def main():
     global LOOSE
     args = sys.argv[1:]

@@ -24,6 +24,15 @@ for _ in range(reps):
 ctx.forward_batch(b, batch)
 for _ in range(max(6, reps // 4)):
     ctx.polymul_batch(a, b, batch)
+# kernel class 0 (round 6): a context on a Barrett-inexact 60-bit modulus -- the reference's own butterflies in the single-pass kernels
+from bench import Q60_INEXACT, PSI60_INEXACT
+ctx0 = ntt.NTTContext(32768, [Q60_INEXACT], [PSI60_INEXACT])
+a0 = synth(torch, batch, 32768, [Q60_INEXACT], dev, 3)
+for _ in range(max(6, reps // 2)):
+    ctx0.forward_batch(a0, batch)
+    ctx0.inverse_batch(a0, batch)
+ctx0.close()
+del a0
 # the latency path (one polynomial: k_lat_fwd_a + k_lat_fwd_b, k_lat_inv_b + k_lat_inv_a, and the three-launch product)
 one, two = a[:32768].clone(), b[:32768].clone()
 for _ in range(max(6, reps // 4)):

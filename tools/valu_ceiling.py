@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r05.json (read by bench.py).
+"""Secondary (VALU) ceiling of the shipped n = 2^15 kernels -> profiles/valu_ceiling_r06.json (read by bench.py).
 
 Compiles ntt-cuda_amd/csrc/kernels_fast_n15.hip to gfx950 assembly, sums the measured steady-state issue cost
 (tools/ubench_issue.hip, profiles/r02_ubench_issue_costs.txt) over the instructions of each kernel's polynomial loop
@@ -55,8 +55,10 @@ def loop_cost(lines, name_part):
     raise SystemExit("kernel %s not found" % name_part)
 
 
-KERNELS = (("k_forward15", "k_forward15ILi4ELb1ELi0"), ("k_inverse15", "k_inverse15ILi4ELb1"), ("k_polymul15", "k_polymul15ILi4ELb1"))
-PROFILE = os.path.join(ROOT, "profiles", "valu_ceiling_r05.json")
+KERNELS = (("k_forward15", "k_forward15ILi4ELb1ELi0"), ("k_inverse15", "k_inverse15ILi4ELb1"), ("k_polymul15", "k_polymul15ILi4ELb1"),
+           # kernel class 0 (round 6): the longest loop of the two-pass kernels is the literal pass
+           ("k_forward15_lit", "k_forward15_litILi15"), ("k_inverse15_lit", "k_inverse15_litILi15"))
+PROFILE = os.path.join(ROOT, "profiles", "valu_ceiling_r06.json")
 
 
 def ceiling_from_asm(lines):
@@ -67,6 +69,7 @@ def ceiling_from_asm(lines):
         res[k] = {"valu_issue_cycles_per_wave": cyc, "valu_instructions_per_wave": nv, "loop_instructions": ni,
                   "cycles_per_polynomial_per_cu": per_poly, "transforms_per_s": CUS * CLOCK_HZ / per_poly}
     res["pairs_per_s"] = 1.0 / (1.0 / res["k_forward15"]["transforms_per_s"] + 1.0 / res["k_inverse15"]["transforms_per_s"])
+    res["literal_pairs_per_s"] = 1.0 / (1.0 / res["k_forward15_lit"]["transforms_per_s"] + 1.0 / res["k_inverse15_lit"]["transforms_per_s"])
     res["source"] = ("tools/valu_ceiling.py: measured steady-state issue cycles per instruction (profiles/r02_ubench_issue_costs.txt) summed "
                      "over the polynomial loop of the shipped <HL 4, near-2^k> kernels, 4 waves per SIMD; transforms_per_s here at a nominal %d CUs x %.2f GHz "
                      "(bench.py re-prices cycles_per_polynomial_per_cu at the clock sampled inside its timed launches); "
@@ -108,7 +111,7 @@ def main():
         bad = drift(res, json.load(open(PROFILE)))
         for b in bad:
             print(b)
-        print("valu ceiling profile %s" % ("DRIFTED: regenerate profiles/valu_ceiling_r05.json" if bad else "in step with the shipped sources"))
+        print("valu ceiling profile %s" % ("DRIFTED: regenerate profiles/valu_ceiling_r06.json" if bad else "in step with the shipped sources"))
         return 1 if bad else 0
     json.dump(res, open(PROFILE, "w"), indent=1)
     print(json.dumps(res, indent=1))
