@@ -567,9 +567,11 @@ def main():
     tpath = newest_profile("traffic_r%02d.json")
     if tpath:
         try:
-            traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
-            traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload, " \
-                             "FETCH_SIZE x 2 per the gfx950 calibration; not collected inside this run)" % os.path.relpath(tpath, ROOT)
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+            traffic_source = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload at commit %s, " \
+                             "FETCH_SIZE x 2 per the gfx950 calibration; not collected inside this run -- tests/test_abi_host.py fails when the " \
+                             "shipped kernels are no longer the ones that were profiled)" % (os.path.relpath(tpath, ROOT), tj.get("commit", "?"))
         except Exception:
             traffic = None
     # the same fraction from the committed rocprofv3 kernel trace (what a reader can reproduce from profiles/): rocprofv3 reads

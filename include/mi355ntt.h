@@ -140,9 +140,15 @@ const mi355ntt_u64* mi355ntt_ctx_psiinv_tables(const mi355ntt_ctx* ctx);
  * host-visible error word; the next call
  * that wants a cooperating launch on that device returns MI355NTT_EHIP (mi355ntt_last_hip_error() = hipErrorLaunchFailure) without
  * launching and clears the condition, so the call after it runs normally.  The data of the launch that gave up is invalid, as after any
- * asynchronous device fault -- but the process keeps its device context (no trap).  This can only happen when another workload holds
- * the device's CUs indefinitely.
+ * asynchronous device fault -- and so is the data of every cooperating launch that was ALREADY ENQUEUED behind it on that device: their
+ * waiting workgroups find the dead mark and end without storing, although the calls that enqueued them have long returned
+ * MI355NTT_OK.  Launches of the other kernels, and calls on other streams that never ask for the cooperating form, neither see nor
+ * report the condition.  mi355ntt_pair_fault_count(device) counts these events and is never reset: a caller that compares it before
+ * and after a stretch of n = 65536 work knows whether all of it is valid.  The process keeps its device context (no trap).  This can
+ * only happen when another workload holds the device's CUs indefinitely.
  * ---------------------------------------------------------------------------------------------- */
+/* cooperating launches on `device` that gave up on a partner since the library was loaded (sticky; see above) */
+unsigned long long mi355ntt_pair_fault_count(int device);
 /* forwardNTT (ntt_60bit.cuh:314-348): one polynomial, prime prime_idx */
 int mi355ntt_forward(const mi355ntt_ctx* ctx, mi355ntt_u64* d_a, unsigned prime_idx, mi355ntt_stream stream);
 /* inverseNTT (ntt_60bit.cuh:350-386) */

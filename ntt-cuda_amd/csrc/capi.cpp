@@ -148,6 +148,7 @@ const char* mi355ntt_strerror(int code)
 }
 
 int mi355ntt_last_hip_error(void) { return g_last_hip_error; }
+unsigned long long mi355ntt_pair_fault_count(int device) { return pair_fault_count(device); }
 const char* mi355ntt_version(void) { return "mi355ntt 0.1 (gfx950)"; }
 
 /* ---------------- host-only helpers ---------------- */

@@ -146,6 +146,7 @@ hipError_t pair_init_current_device();                  // allocates the current
 PairSlot* pair_acquire(hipStream_t s, hipError_t* status = nullptr);
 void pair_release(PairSlot* slot, hipStream_t s);
 unsigned* pair_flags(PairSlot* slot);
+unsigned long long pair_fault_count(int device);        // launches that gave up on a partner on this device so far (never reset)
 // Watchdog of the spinning workgroups, in ticks of the 100 MHz constant clock (s_memrealtime): a partner that has not become resident
 // after this long means another tenant holds the CUs indefinitely.  The workgroup then GIVES UP instead of hanging (or trapping, which
 // would take the process's device context with it): it sets the last word of the flag buffer -- a workgroup of this or of a later

@@ -99,6 +99,7 @@ struct PairSlot {
     hipEvent_t done = nullptr;
     hipStream_t owner = nullptr;
     bool in_flight = false;
+    unsigned long long faults = 0;           // sticky: launches of this device that gave up on a partner (mi355ntt_pair_fault_count)
     volatile unsigned* h_err = nullptr;      // host-mapped: written by a workgroup that gave up on its partner (kernels.hpp, watchdog)
     unsigned* d_err = nullptr;               // the same word as the device sees it
 };
@@ -201,6 +202,7 @@ PairSlot* pair_acquire(hipStream_t s, hipError_t* status)
         // behind whatever is still queued on this stream (every queued pair launch finds the dead word and returns at once) and
         // report; the next call starts from a clean slot.
         *p.h_err = 0;
+        p.faults++;
         (void)hipMemsetAsync(p.d_flags, 0, kPairLiveWords * sizeof(unsigned), s);
         (void)hipMemsetAsync(p.d_flags + kPairDeadWord, 0, sizeof(unsigned), s);
         p.owner = s;
@@ -220,6 +222,13 @@ void pair_release(PairSlot* p, hipStream_t s)
     g_pair_mutex.unlock();
 }
 unsigned* pair_flags(PairSlot* p) { return p->d_flags; }
+unsigned long long pair_fault_count(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return 0;
+    std::lock_guard<std::mutex> lock(g_pair_mutex);
+    // (an event nobody has asked about yet counts as well: the error word is still up)
+    return g_pair[device].faults + ((g_pair[device].h_err && *g_pair[device].h_err) ? 1ull : 0ull);
+}
 
 
 // ------------------------------------------------------------------------------------------------

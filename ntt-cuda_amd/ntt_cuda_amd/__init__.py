@@ -29,6 +29,7 @@ EINVAL, EUNSUPPORTED, EHIP, ENOMEM, EPARAM = -1, -2, -3, -4, -5
 _SIGNATURES = {
     "mi355ntt_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "mi355ntt_last_hip_error": (ctypes.c_int, []),
+    "mi355ntt_pair_fault_count": (ctypes.c_ulonglong, [ctypes.c_int]),
     "mi355ntt_version": (ctypes.c_char_p, []),
     "mi355ntt_bit_length": (ctypes.c_uint, [u64]),
     "mi355ntt_barrett_mu": (u64, [u64, ctypes.c_uint]),

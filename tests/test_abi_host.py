@@ -206,6 +206,25 @@ def test_valu_ceiling_profile_matches_shipped_kernels(n15_compile):
     assert r.returncode == 0, r.stdout[-2000:]
 
 
+def test_traffic_profile_belongs_to_the_shipped_kernels(native):
+    """bench.py prints roofline.traffic from profiles/traffic_rNN.json -- a committed figure, not one collected in the run.  The file
+    records the instruction streams of the kernels it was taken on (tools/codeobj_digest.py over the library that ran); a change of
+    k_forward15 / k_inverse15 / k_polymul15 or their class-0 counterparts without new FETCH_SIZE / WRITE_SIZE passes
+    (tools/profile_traffic.sh) fails here, as the VALU-ceiling profile does above."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj_digest
+    import bench
+    path = bench.newest_profile("traffic_r%02d.json")
+    prof = json.load(open(path))
+    assert prof.get("commit") and isinstance(prof.get("kernel_digest"), dict) and len(prof["kernel_digest"]) >= 5, path
+    now = codeobj_digest.named_digests(os.path.join(ROOT, "ntt-cuda_amd", "build", "kernels_fast_n15.hip.o"))
+    stale = [k for k, h in prof["kernel_digest"].items() if now.get(k) != h]
+    assert not stale, ("the shipped kernels differ from the ones %s was taken on: re-run tools/profile_traffic.sh" % os.path.relpath(path, ROOT), stale)
+    for k in ("k_forward15", "k_inverse15", "k_forward15_lit", "k_inverse15_lit"):
+        assert 1.0 <= prof[k]["ratio"] < 1.06, (k, prof[k]["ratio"])      # measured traffic within 6 % of the algorithmic bytes
+
+
 def test_host_objects_under_asan_ubsan(native, tmp_path):
     """The host side of the C ABI (capi.cpp, hostparams.cpp, bfv_host.cpp, shard.cpp) compiled by g++ with AddressSanitizer and
     UndefinedBehaviorSanitizer and linked in front of libmi355ntt.so (which supplies the kernel launchers): tests/cpp/host_sanitize.cpp

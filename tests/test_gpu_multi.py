@@ -59,6 +59,55 @@ def test_shards_object_across_real_devices(native, oracle, gpu):
         c.close()
 
 
+def _polymul_over_shards(native, oracle, devices):
+    """MI355NTT_OP_POLYMUL through mi355ntt_shards_transform: every shard multiplies its polynomials with its own second operands (the
+    fused product, in the NTT domain); against the whole-batch call on the first device, word for word"""
+    import torch
+    world = len(devices)
+    n, qs, psis = 32768, P.Q60, P.PSI60
+    num = 4 * 11 * world + 2                              # ragged: the last shard is shorter
+    ctxs = [native.NTTContext(n, qs, psis, device=d) for d in devices]
+    a = oracle.synth_batch(n, num, qs, 77).reshape(num, n)
+    b = oracle.synth_batch(n, num, qs, 78).reshape(num, n)
+    d0 = "cuda:%d" % devices[0]
+    bh = native.to_device(b, d0)
+    ctxs[0].forward_batch(bh, num)
+    want = native.to_device(a, d0)
+    ctxs[0].polymul_batch(want, bh, num)
+    torch.cuda.synchronize()
+    bh_host = native.to_host(bh).reshape(num, n)
+    sh = native.ShardSet(ctxs, max_polys_per_piece=64)
+    parts, bparts = [], []
+    for r in range(world):
+        first, count = native.shard_range(num, len(qs), r, world)
+        dev = "cuda:%d" % devices[r]
+        parts.append(native.to_device(a[first: first + count], dev) if count else torch.empty(0, dtype=torch.int64, device=dev))
+        bparts.append(native.to_device(bh_host[first: first + count], dev) if count else torch.empty(0, dtype=torch.int64, device=dev))
+    sh.transform(native.OP_POLYMUL, parts, num, bhat=bparts)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    got = torch.cat([p_.to(d0).reshape(-1, n) for p_ in parts if p_.numel()])
+    assert torch.equal(got, want.reshape(num, n))
+    sh.close()
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_shards_polymul_across_real_devices(native, oracle, gpu):
+    """round 6: the fused product across devices"""
+    nd = _devices()
+    if nd < 2:
+        pytest.skip("one GPU visible (the same call over logical shards on one device: test_shards_polymul_logical_shards_one_device)")
+    _polymul_over_shards(native, oracle, list(range(min(nd, 8))))
+
+
+@pytest.mark.gpu
+def test_shards_polymul_logical_shards_one_device(native, oracle, gpu):
+    """... and the same code path with four logical shards on the one device this box has (what one GPU allows)"""
+    _polymul_over_shards(native, oracle, [0, 0, 0, 0])
+
+
 @pytest.mark.gpu
 def test_bench_over_rccl_across_real_devices(native, gpu):
     """bench.py --gpus N as the driver launches it (torch.distributed.run, one rank per GPU, RCCL): the line carries the RCCL world
@@ -75,3 +124,4 @@ def test_bench_over_rccl_across_real_devices(native, gpu):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == world and line["collective"]["world_size_observed"] == world and line["collective"]["backend"] == "nccl"
     assert line["value"] > 0 and line["end_to_end"]["pairs_per_s"] > 0 and line["end_to_end"]["global_batch"] == world * 256
+    assert 0 < line["per_rank_pairs_per_s"]["min"] <= line["per_rank_pairs_per_s"]["max"]

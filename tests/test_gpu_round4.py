@@ -306,3 +306,6 @@ def test_bench_collective_bracket_over_rccl_world_size_1(native, gpu):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
     assert "error" not in out.get("end_to_end", {}), out.get("end_to_end")
+    # round 6: the slowest / fastest rank from the same all-reduce as the contract's MAX, the settled flag and the rounds beside `value`
+    assert out["per_rank_pairs_per_s"]["min"] <= out["per_rank_pairs_per_s"]["max"] and abs(out["per_rank_pairs_per_s"]["min"] - out["value"]) < 1e-6 * out["value"]
+    assert isinstance(out["settled"], bool) and out["rounds"]["pairs_per_s_median"] > 0 and out["roofline"]["rounds_pairs_per_s"]["median"] > 0

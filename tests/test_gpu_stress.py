@@ -284,6 +284,7 @@ load, s1 = torch.cuda.Stream(), torch.cuda.Stream()
 # How many CUs must stay free for ONE workgroup to start is the dispatcher's business (workgroups are dealt to the XCDs round-robin;
 # on the development boxes one free CU starts nothing, two free CUs -- in two XCDs -- start two partner-less workgroups): try a few.
 wrong, gave_up_after, held = False, 0.0, 0
+faults0 = ntt.lib().mi355ntt_pair_fault_count(0)
 for free in (2, 4, 1, 3, 6):
     w = a.clone(); torch.cuda.synchronize()
     ctx.occupy(cus - free, 300000, stream=load)
@@ -309,7 +310,8 @@ untouched = torch.equal(w2, a)
 w3 = a.clone(); torch.cuda.synchronize()
 ctx.forward_batch(w3, num, stream=s1)
 torch.cuda.synchronize()
-print("WATCHDOG wrong=%d held=%d seconds=%.2f code=%s hip=%s untouched=%d recovered=%d" % (wrong, held, gave_up_after, code, hip, untouched, torch.equal(w3, good)))
+print("WATCHDOG wrong=%d held=%d seconds=%.2f code=%s hip=%s untouched=%d recovered=%d faults=%d" % (wrong, held, gave_up_after, code, hip, untouched, torch.equal(w3, good),
+      ntt.lib().mi355ntt_pair_fault_count(0) - faults0))
 ctx.close()
 """
 
@@ -329,3 +331,4 @@ def test_pair_watchdog_gives_up_without_killing_the_context(native, gpu):
     assert float(f["seconds"]) < 2.0, line
     assert int(f["code"]) == native.EHIP and int(f["hip"]) == 719, line          # hipErrorLaunchFailure
     assert f["untouched"] == "1" and f["recovered"] == "1", line
+    assert int(f["faults"]) >= 1, line                   # (sticky: mi355ntt_pair_fault_count still tells after the condition was cleared)
