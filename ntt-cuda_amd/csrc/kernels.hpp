@@ -143,7 +143,8 @@ constexpr unsigned kPairFlagWords = 2048;               // zeroed 32-bit words; 
 hipError_t pair_init_current_device();                  // allocates the current device's slot (idempotent)
 // status (may be null): hipErrorLaunchFailure when an EARLIER pair launch on this device gave up on a partner (see the watchdog below) --
 // the slot is then cleaned (flags zeroed in stream order) and null returned: the caller reports the error instead of launching
-PairSlot* pair_acquire(hipStream_t s, hipError_t* status = nullptr);
+// wait = true: a slot held by another stream's launch in flight is waited for on `s` (hipStreamWaitEvent) instead of refused
+PairSlot* pair_acquire(hipStream_t s, hipError_t* status = nullptr, bool wait = false);
 void pair_release(PairSlot* slot, hipStream_t s);
 unsigned* pair_flags(PairSlot* slot);
 unsigned long long pair_fault_count(int device);        // launches that gave up on a partner on this device so far (never reset)

@@ -174,7 +174,7 @@ unsigned long long pair_watchdog_ticks()
     return ticks;
 }
 
-PairSlot* pair_acquire(hipStream_t s, hipError_t* status)
+PairSlot* pair_acquire(hipStream_t s, hipError_t* status, bool wait)
 {
     if (status) *status = hipSuccess;
     static const bool off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;      // (A/B measurements)
@@ -190,7 +190,9 @@ PairSlot* pair_acquire(hipStream_t s, hipError_t* status)
     bool ok = pair_init_locked(p) == hipSuccess && p.d_flags != nullptr;
     if (ok && p.in_flight && p.owner != s) {
         if (hipEventQuery(p.done) == hipSuccess) p.in_flight = false;
-        else ok = false;
+        // wait: the caller prefers its cooperating launch ORDERED BEHIND the other stream's to the single-workgroup form (the device
+        // then still has one such kernel in flight at a time)
+        else if (!(wait && hipStreamWaitEvent(s, p.done, 0) == hipSuccess)) ok = false;
     }
     if (!ok) {
         (void)hipGetLastError();                                    // (hipErrorNotReady of the query is not an error of this call)

@@ -17,6 +17,8 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -853,9 +855,14 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     PairSlot* slot = nullptr;
     if (split && num >= (FWD ? kPair30MinPolysFwd : kPair30MinPolysInv) && (pgrid = pair_grid(cnt)) != 0) {
         hipError_t pst = hipSuccess;
-        if ((slot = pair_acquire(s, &pst)) == nullptr) pgrid = 0;
+        // (round 6: a call that finds the slot held by ANOTHER stream's pair launch queues up behind it instead of taking the stage launch
+        // next to it -- see DESIGN.md, open issues: the first such call of a long-running process returned wrong words in the full test
+        // suite, in that constellation only, and the cause has not been found)
+        if ((slot = pair_acquire(s, &pst, true)) == nullptr) pgrid = 0;
         if (pst != hipSuccess) return pst;                // (an earlier pair launch gave up on a partner: reported here, nothing launched)
     }
+    static const bool trace = std::getenv("MI355NTT_TRACE30") != nullptr;
+    if (trace) std::fprintf(stderr, "ntt30 %s n=%u num=%u stream=%p pair_grid=%u epoch=%u sc=%p\n", FWD ? "fwd" : "inv", n, num, (void*)s, pgrid, epoch, (void*)sc);
     const unsigned ninv_k = (pgrid && !FWD) ? (unsigned)(((u64)ninv_native * ((q + 1) / 2)) % q) : ninv_native;
     if (pgrid) {
         k_ntt30_prepare<<<64, 256, 0, s>>>(d_tab, n, q, ninv_k, split, FWD ? 1u : 0u, sc, epoch);
