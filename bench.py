@@ -136,6 +136,9 @@ def parse():
     ap.add_argument("--prewarm-seconds", type=float, default=1.5,
                     help="untimed, time-based pre-warm: back-to-back steps for at least this long before the W warm-up steps (the SMU "
                          "takes about a second of load to settle the clocks under the package-power limit)")
+    ap.add_argument("--blocking-sync", action="store_true",
+                    help="A/B switch: do not poll an event in front of the bracket's barrier + synchronize (the host then sleeps in "
+                         "hipDeviceSynchronize; its wake-up latency lands in the timed region)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets two ranks share one GPU for a dry run)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time scatter -> forward+inverse -> gather from a rank-0-resident batch (SURVEY.md 8(e), report 2)")
@@ -466,6 +469,16 @@ def main():
         ctx.inverse_batch(a, batch)
 
     def barrier():
+        # the contract's bracket: barrier + torch.cuda.synchronize().  In front of it the host polls an event behind the work queued so
+        # far, so that hipDeviceSynchronize() returns without sleeping on an interrupt: one round-6 run read 0.3398 ms per step by wall
+        # clock against 0.3316 ms by HIP events over the same 20 steps (0.16 ms of wake-up latency in a 6.8 ms region).  A/B on one box
+        # (tools/probe/bench_sync_ab.sh, 4 runs each): wall - events = 2 us per step either way, values within the +-1.5 % a 20-step
+        # sample scatters by (the 10-step rounds of one run span 3.03-3.16 M) -- kept because it bounds that latency, not because it gains
+        if not args.blocking_sync:
+            ev = torch.cuda.Event()
+            ev.record()
+            while not ev.query():
+                pass
         if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
@@ -639,6 +652,8 @@ def main():
                                             "(extras.power_sustained, profiles/r04_power_cap_and_overlap.txt)" % (os.path.relpath(vpath, ROOT) if vpath else None)},
         "kernel_ms": {"k_forward15": fwd_ms, "k_inverse15": inv_ms, "step_by_events": step_ms_events},
         "settled": settled,
+        "bracket": "barrier + torch.cuda.synchronize() on both sides" + ("" if args.blocking_sync else
+                   "; the host polls an event behind the queued work first, so the synchronize returns without a sleep / interrupt wake-up"),
         "per_rank_pairs_per_s": {"min": batch * args.steps / elapsed, "max": batch * args.steps / elapsed_min,
                                  "what": "slowest and fastest rank over the same K steps (value = world x batch x K / the slowest rank's time)"},
         "prewarm": {"seconds": prewarm_s, "steps": prewarm_steps, "how": "untimed, time-based: chunks of %d steps back to back, at most two chunks queued, until --prewarm-seconds of wall clock have passed; then the W warm-up steps" % chunk_steps},
