@@ -247,15 +247,20 @@ int mi355ntt_ctx_probed_clock_mhz(const mi355ntt_ctx* ctx, double* mhz);
  * the exact transform, so those calls run the THROUGHPUT kernels: on first sight of a (device, n, moduli, mu,
  * bit_length, table address) the library reads the root out of the table, derives a context, compares the caller's
  * table with the derived one, and keeps the context (<= 32, least recently used evicted; first sight synchronises
- * the call's stream -- the table may have been filled asynchronously on it -- and reads the table from the host).  Any other call (hand-made mu, a table that is not root^bitrev(i), a Barrett-inexact modulus, n outside
+ * the call's stream -- the table may have been filled asynchronously on it -- and reads the table from the host).  A set with a
+ * Barrett-inexact modulus derives a class-0 context (the reference's own butterflies in the single-pass kernels: the reference's
+ * words, see the arithmetic contract above).  Any other call (hand-made mu, a table that is not root^bitrev(i), n outside
  * 2^11..2^16, a table that is not 16-byte aligned) follows Algorithm 7 (singleBarrett, ntt_60bit.cuh:44-61) literally with the caller's
- * numbers: the literal kernels (the stages inside 2^14 coefficients out of LDS + one stage launch at n = 2^15 = 2 passes
+ * numbers: the literal stage kernels (the stages inside 2^14 coefficients out of LDS + one stage launch at n = 2^15 = 2 passes
  * over memory; the reference makes 4 and 5).
  *   The reference reads the table on every call, so a cached context must never outlive the table's contents (a
  * freed table whose address is handed out again, a table rewritten in place).  Default, CHECKED: in front of every
  * transform a small kernel compares the caller's table with the context's on the device (stream-ordered, no host
  * synchronisation), the throughput kernel runs only if they are equal and the literal kernels only if they are not:
- * always the caller's table's result, for a few microseconds per call.  mi355ntt_raw_trust_tables() is the caller's promise that a table stays
+ * always the caller's table's result, for a few microseconds per call.  The words the comparison writes are per (table, stream): calls on
+ * different streams share nothing and a call never touches a stream other than its own (up to 16 streams per table; calls on further
+ * streams, and checked calls on a CAPTURING stream, run the literal stage kernels).  A table found changed makes its next call derive a
+ * new context.  mi355ntt_raw_trust_tables() is the caller's promise that a table stays
  * as it is: calls on it skip the check (and n = 2^16, whose split path cannot be guarded, runs the throughput kernels
  * only then).  mi355ntt_raw_cache_clear() forgets everything; MI355NTT_RAW_LITERAL=1 in the environment disables the
  * routing.  Calls run on the CURRENT device, as the reference's do.

@@ -549,6 +549,12 @@ static int check_raw_n(unsigned n) { return (is_pow2(n) && n >= 2 && n <= (1u <<
 // MI355NTT_RAW_LITERAL=1 in the environment disables the routing).
 namespace {
 
+struct RawStreamSlot {
+    hipStream_t stream = nullptr;
+    void* d_primes_alloc = nullptr;    // (num_primes + 1) PrimeDev records: [0] = guard record, [1..] = the context's
+};
+constexpr size_t kRawStreamSlots = 16;
+
 struct RawEntry {
     int device = 0;
     unsigned n = 0, division = 0;
@@ -561,9 +567,12 @@ struct RawEntry {
     // checked mode (default): the table is compared with the context's in front of every transform (guard words, kernels.hpp)
     bool trusted = false;              // the caller promised not to rewrite the table: no per-call comparison
     unsigned epoch = 0;
-    hipEvent_t ev = nullptr;           // hand-over of the guard words to a call that arrives on another stream (recorded then, not per call)
-    hipStream_t last_stream = nullptr;
-    bool used = false;
+    // The guard words of the checked calls belong to ONE stream: every stream that calls with this entry gets a copy of the context's
+    // PrimeDev array with a guard record of its own in front (a few KB; the tables are shared, they are read-only).  Nothing is handed
+    // from stream to stream, so no call ever touches a stream other than the one it was given -- which the caller may have destroyed
+    // by then (until round 6 an event was recorded on the previous caller's stream: a use-after-free when that caller's thread had
+    // finished, found by tests/cpp/threads_test.cpp).  Streams beyond kRawStreamSlots run the literal kernels (they share nothing).
+    std::vector<RawStreamSlot> slots;
     // host-mapped word the comparison kernel sets when the table no longer holds what the context was derived from: the next call
     // derives a new context (twice; an entry whose table keeps changing then stays on the literal kernels)
     volatile unsigned* h_changed = nullptr;
@@ -630,13 +639,43 @@ mi355ntt_ctx* raw_derive(int device, unsigned n, unsigned division, bool inverse
     return c;
 }
 
+void raw_slots_release(RawEntry& e)
+{
+    for (RawStreamSlot& sl : e.slots)
+        if (sl.d_primes_alloc) (void)hipFree(sl.d_primes_alloc);       // (hipFree waits for the launches that still read it)
+    e.slots.clear();
+}
+
+// The guard record + PrimeDev copy of entry e for stream s (g_raw_mutex held); null: no slot left or no memory -- the call then runs
+// the literal kernels.  Filled on s itself, in front of the first launch that reads it.
+void* raw_slot_for(RawEntry& e, hipStream_t s)
+{
+    for (RawStreamSlot& sl : e.slots)
+        if (sl.stream == s) return sl.d_primes_alloc;
+    if (e.slots.size() >= kRawStreamSlots) return nullptr;
+    const mi355ntt_ctx* c = e.ctx;
+    const size_t rec = fast_prime_record_bytes(), bytes = (size_t)(c->num_primes + 1) * rec;
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemsetAsync(d, 0, rec, s) != hipSuccess ||
+        hipMemcpyAsync(static_cast<char*>(d) + rec, c->fast.d_primes, bytes - rec, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        return nullptr;
+    }
+    RawStreamSlot sl;
+    sl.stream = s;
+    sl.d_primes_alloc = d;
+    e.slots.push_back(sl);
+    return d;
+}
+
 void raw_entry_release(RawEntry& e)
 {
+    raw_slots_release(e);
     if (e.ctx) mi355ntt_ctx_destroy(e.ctx);
-    if (e.ev) (void)hipEventDestroy(e.ev);
     if (e.h_changed) (void)hipHostFree(const_cast<unsigned*>(e.h_changed));
     e.ctx = nullptr;
-    e.ev = nullptr;
     e.h_changed = nullptr;
     e.d_changed = nullptr;
 }
@@ -690,10 +729,10 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
     if (e && e->ctx && e->h_changed && *e->h_changed) {
         (void)hipDeviceSynchronize();
         *e->h_changed = 0;
+        raw_slots_release(*e);                            // (copies of the old context's per-prime records)
         mi355ntt_ctx_destroy(e->ctx);
         e->ctx = ++e->rederived > 2 ? nullptr : raw_derive(e->device, e->n, e->division, e->inverse, e->tab, e->q, e->mu, e->bits);
         (void)hipGetLastError();
-        e->used = false;
         e->trusted = false;
     }
     const mi355ntt_ctx* c = e ? e->ctx : nullptr;
@@ -708,20 +747,11 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
-    // The guard words belong to the stream that used them last.  A call on another stream is ordered behind everything that stream has
-    // enqueued -- an event recorded on it NOW (round 6; until round 5 every call recorded one behind itself, a barrier packet and 6 us
-    // of idle GPU per call in the kernel trace: profiles/r06_raw_checked_calls.txt).  A stream that has been destroyed or is
-    // capturing by now cannot hand over: the call then runs the literal kernels with the caller's table, which share nothing.
-    if (e->used && e->last_stream != s) {
-        hipStreamCaptureStatus lcap = hipStreamCaptureStatusNone;
-        bool handed = hipStreamIsCapturing(e->last_stream, &lcap) == hipSuccess && lcap == hipStreamCaptureStatusNone;
-        if (handed && !e->ev) handed = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) == hipSuccess;
-        handed = handed && hipEventRecord(e->ev, e->last_stream) == hipSuccess && hipStreamWaitEvent(s, e->ev, 0) == hipSuccess;
-        if (!handed) {
-            (void)hipGetLastError();
-            return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
-        }
-    }
+    // The guard words this call uses are its stream's own (raw_slot_for): no event, no wait, nothing shared with calls on other streams
+    // (until round 5 every call recorded an event behind itself -- a barrier packet and 6 us of idle GPU per call in the kernel trace,
+    // profiles/r06_raw_checked_calls.txt).
+    void* const slot = raw_slot_for(*e, s);
+    if (!slot) return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (!e->h_changed) {
         void* h = nullptr;
         void* d = nullptr;
@@ -734,16 +764,15 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
             (void)hipGetLastError();
         }
     }
-    unsigned* guard = static_cast<unsigned*>(c->fast.d_primes_alloc);
+    unsigned* guard = static_cast<unsigned*>(slot);
+    FastTables t = c->fast;                               // the context's tables with this stream's guard record + per-prime records
+    t.d_primes_alloc = slot;
+    t.d_primes = static_cast<char*>(slot) + fast_prime_record_bytes();
     if (++e->epoch == 0) e->epoch = 1;
     if ((err = compat_tables_check(d_tab, inverse ? c->d_psiinv : c->d_psi, n, division, guard, e->epoch, s, e->d_changed)) != hipSuccess) return err;
-    err = inverse ? run_inverse(c, d_a, num, division, kGuardBit, s) : run_forward(c, d_a, num, division, kGuardBit, s);
+    err = inverse ? fast_inverse_batch(t, d_a, num, division, kGuardBit, s) : fast_forward_batch(t, d_a, num, division, kGuardBit, s);
     if (err != hipSuccess) return err;
-    err = inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s, guard) : compat_forward_batch(d_a, n, d_tab, num, division, m, s, guard);
-    if (err != hipSuccess) return err;
-    e->used = true;
-    e->last_stream = s;
-    return hipSuccess;
+    return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s, guard) : compat_forward_batch(d_a, n, d_tab, num, division, m, s, guard);
 }
 
 }  // namespace

@@ -101,6 +101,7 @@ struct FastTables {
 // split_fwd (n = 2^16 contexts only, else null): per (virtual) prime the twiddle of the stage that couples the two halves
 // literal: kernel class HL_LIT (hl = 0) -- the transforms of this context return the reference's own words (singleBarrett with one
 // conditional subtraction carried through the stages, ntt_core.cuh), for contexts with a Barrett-inexact modulus
+size_t fast_prime_record_bytes();     // sizeof(PrimeDev): d_primes_alloc holds num_primes + 1 of them, [0] = guard record
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
                               const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd = nullptr,
                               const u64* split_inv = nullptr, bool literal = false);
@@ -143,8 +144,7 @@ constexpr unsigned kPairFlagWords = 2048;               // zeroed 32-bit words; 
 hipError_t pair_init_current_device();                  // allocates the current device's slot (idempotent)
 // status (may be null): hipErrorLaunchFailure when an EARLIER pair launch on this device gave up on a partner (see the watchdog below) --
 // the slot is then cleaned (flags zeroed in stream order) and null returned: the caller reports the error instead of launching
-// wait = true: a slot held by another stream's launch in flight is waited for on `s` (hipStreamWaitEvent) instead of refused
-PairSlot* pair_acquire(hipStream_t s, hipError_t* status = nullptr, bool wait = false);
+PairSlot* pair_acquire(hipStream_t s, hipError_t* status = nullptr);
 void pair_release(PairSlot* slot, hipStream_t s);
 unsigned* pair_flags(PairSlot* slot);
 unsigned long long pair_fault_count(int device);        // launches that gave up on a partner on this device so far (never reset)

@@ -174,7 +174,7 @@ unsigned long long pair_watchdog_ticks()
     return ticks;
 }
 
-PairSlot* pair_acquire(hipStream_t s, hipError_t* status, bool wait)
+PairSlot* pair_acquire(hipStream_t s, hipError_t* status)
 {
     if (status) *status = hipSuccess;
     static const bool off = std::getenv("MI355NTT_NO_PAIR16") != nullptr;      // (A/B measurements)
@@ -190,9 +190,7 @@ PairSlot* pair_acquire(hipStream_t s, hipError_t* status, bool wait)
     bool ok = pair_init_locked(p) == hipSuccess && p.d_flags != nullptr;
     if (ok && p.in_flight && p.owner != s) {
         if (hipEventQuery(p.done) == hipSuccess) p.in_flight = false;
-        // wait: the caller prefers its cooperating launch ORDERED BEHIND the other stream's to the single-workgroup form (the device
-        // then still has one such kernel in flight at a time)
-        else if (!(wait && hipStreamWaitEvent(s, p.done, 0) == hipSuccess)) ok = false;
+        else ok = false;
     }
     if (!ok) {
         (void)hipGetLastError();                                    // (hipErrorNotReady of the query is not an error of this call)
@@ -234,6 +232,8 @@ unsigned long long pair_fault_count(int device)
 
 
 // ------------------------------------------------------------------------------------------------
+size_t fast_prime_record_bytes() { return sizeof(PrimeDev); }
+
 hipError_t fast_tables_create(FastTables* t, unsigned n, unsigned num_primes, const PrimeParams* prime, const u64* h_psi,
                               const u64* h_psiinv, const u64* d_psi, const u64* d_psiinv, const u64* split_fwd, const u64* split_inv, bool literal)
 {

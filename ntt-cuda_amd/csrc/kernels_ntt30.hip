@@ -747,7 +747,11 @@ Scratch30* scratch_for(hipStream_t s)
     if (it != g_scratch.end()) return it->second;
     Scratch30* p = nullptr;
     if (hipMalloc((void**)&p, sizeof(Scratch30)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, offsetof(Scratch30, tw)) != hipSuccess) {
+    // The header (guard words) is zeroed ON THE CALLER'S STREAM, in front of the first k_ntt30_prepare.  Up to round 6 this was a
+    // hipMemset: asynchronous to the host for device memory and enqueued on the NULL stream, with which a non-blocking stream (every
+    // torch stream) is not ordered -- with the device busy (another stream's pair launch holding every CU) it could land after the
+    // first call's prepare kernel had written the guard words, and the guarded literal leg then transformed the data a second time.
+    if (hipMemsetAsync(p, 0, offsetof(Scratch30, tw), s) != hipSuccess) {
         (void)hipFree(p);
         return nullptr;
     }
@@ -855,10 +859,7 @@ hipError_t run30(unsigned* d_a, unsigned n, const unsigned* d_tab, unsigned num,
     PairSlot* slot = nullptr;
     if (split && num >= (FWD ? kPair30MinPolysFwd : kPair30MinPolysInv) && (pgrid = pair_grid(cnt)) != 0) {
         hipError_t pst = hipSuccess;
-        // (round 6: a call that finds the slot held by ANOTHER stream's pair launch queues up behind it instead of taking the stage launch
-        // next to it -- see DESIGN.md, open issues: the first such call of a long-running process returned wrong words in the full test
-        // suite, in that constellation only, and the cause has not been found)
-        if ((slot = pair_acquire(s, &pst, true)) == nullptr) pgrid = 0;
+        if ((slot = pair_acquire(s, &pst)) == nullptr) pgrid = 0;
         if (pst != hipSuccess) return pst;                // (an earlier pair launch gave up on a partner: reported here, nothing launched)
     }
     static const bool trace = std::getenv("MI355NTT_TRACE30") != nullptr;

@@ -12,6 +12,10 @@
 // tests/test_threads.py builds and runs it.   usage: threads_test [threads = 8] [iterations = 4]
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -185,8 +189,24 @@ static void raw_section()
     printf("%-58s %u threads x %u calls: %s\n", "raw API, 40 tables through a cache of 32", THREADS, ITERS * NT, fails.load() == before ? "ok" : "FAILED");
 }
 
+// a crash must not be silent: where it happened goes to stderr (the Python side prints it with the assertion)
+static void on_fatal_signal(int sig)
+{
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "threads_test: fatal signal, backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int main(int argc, char** argv)
 {
+    signal(SIGSEGV, on_fatal_signal);
+    signal(SIGBUS, on_fatal_signal);
+    signal(SIGABRT, on_fatal_signal);
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     if (argc > 1) THREADS = (unsigned)atoi(argv[1]);
     if (argc > 2) ITERS = (unsigned)atoi(argv[2]);
     const std::vector<u64> q60 = {1152921504606584833ULL, 1152921504598720513ULL, 1152921504597016577ULL, 1152921504595968001ULL};

@@ -158,3 +158,54 @@ def test_raw_calls_on_an_inexact_modulus_run_the_single_pass_kernels(native, ora
         torch.cuda.synchronize()
         assert np.array_equal(native.to_host(d).reshape(num, n), want_i)
     native.raw_cache_clear()
+
+
+def test_checked_raw_calls_share_nothing_between_streams(native, oracle, gpu):
+    """Checked forwardNTT_batch / inverseNTT_batch calls with ONE table from twenty streams -- more than an entry keeps guard records
+    for (16: the others run the literal stage kernels), interleaved so that every call finds the entry last used by another stream,
+    some of the streams gone by the time the next call arrives: every word the oracle's, also after the table was rewritten in place
+    (the comparison's words are per stream: no call waits for, or records on, a stream that is not its own)."""
+    import gc
+    import torch
+    n, num = 4096, 24
+    qs = list(P.Q60)
+    psis = [pow(w, 32768 // n, q) for w, q in zip(P.PSI60, qs)]          # (PSI60: primitive 2 * 32768-th roots)
+    prm = oracle.Params(n, qs, psis)
+    mod = native.Moduli(qs)
+    tf = torch.from_numpy(prm.psi_tabs.view(np.int64).reshape(len(qs), n)).cuda()
+    ti = torch.from_numpy(prm.psiinv_tabs.view(np.int64).reshape(len(qs), n)).cuda()
+    a = oracle.synth_batch(n, num, qs, 77).reshape(num, n)
+    want_f = oracle.forward_batch(a.copy(), prm).reshape(num, n)
+    streams = [torch.cuda.Stream() for _ in range(20)]
+    bufs = [native.to_device(a) for _ in streams]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for s, d in zip(streams, bufs):
+            native.forwardNTT_batch(d, n, tf, num, len(qs), mod, stream=s)
+        for i, (s, d) in enumerate(zip(streams, bufs)):
+            s.synchronize()
+            assert np.array_equal(native.to_host(d).reshape(num, n), want_f), ("forward", rep, i)
+        for s, d in zip(reversed(streams), reversed(bufs)):
+            native.inverseNTT_batch(d, n, ti, num, len(qs), mod, stream=s)
+        for i, (s, d) in enumerate(zip(streams, bufs)):
+            s.synchronize()
+            assert np.array_equal(native.to_host(d).reshape(num, n), a), ("inverse", rep, i)
+        if rep == 0:                    # half of the streams go away; new ones (possibly with the same handles) take their place
+            for k in range(0, 20, 2):
+                streams[k] = None
+            gc.collect()
+            for k in range(0, 20, 2):
+                streams[k] = torch.cuda.Stream()
+    # the table rewritten in place: every stream's next call follows it
+    psis2 = [pow(int(w), 5, int(q)) for w, q in zip(psis, qs)]
+    prm2 = oracle.Params(n, qs, psis2)
+    torch.cuda.synchronize()
+    tf.copy_(torch.from_numpy(prm2.psi_tabs.view(np.int64).reshape(len(qs), n)))
+    torch.cuda.synchronize()
+    want2 = oracle.forward_batch(a.copy(), prm2).reshape(num, n)
+    for s, d in zip(streams, bufs):
+        native.forwardNTT_batch(d, n, tf, num, len(qs), mod, stream=s)
+    for i, (s, d) in enumerate(zip(streams, bufs)):
+        s.synchronize()
+        assert np.array_equal(native.to_host(d).reshape(num, n), want2), ("rewritten table", i)
+    native.raw_cache_clear()

@@ -209,9 +209,9 @@ def test_gpu_30bit_n65536_pair_launch_matches_oracle(native, oracle, gpu, num):
     native.forward30(d_c, n, q, prm.mu, bits, d_psi, num, stream=s1)
     native.forward30(d_d, n, q, prm.mu, bits, d_psi, num, stream=s2)
     torch.cuda.synchronize()
-    # (round 6: a stream that finds the pair slot held by the other one now queues up behind it.  Until then it took the stage launch
-    # NEXT to the other stream's pair launch, and inside the full suite -- never in this file alone -- the first such call returned
-    # wrong words: DESIGN.md, open issues)
+    # (the second stream finds the pair slot held and takes the stage launch NEXT to the first stream's pair launch.  Its very first call
+    # also allocates the stream's scratch table: until round 6 the table's guard words were zeroed by a hipMemset on the null stream,
+    # which could land AFTER the call's prepare kernel on a busy device -- inside the full suite this assertion failed, never alone)
     assert np.array_equal(host32(d_c), A), "two streams: first stream"
     assert np.array_equal(host32(d_d), A), "two streams: second stream"
     # captured (the first call on the capture stream happens outside the capture: it allocates the stream's scratch table)
