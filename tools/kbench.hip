@@ -52,7 +52,8 @@ int main(int argc, char** argv)
     CK(hipMemcpy(a, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtw, tw.data(), n * sizeof(TwPair), hipMemcpyHostToDevice));
     CK(hipMemcpy(dp, &d, sizeof(d), hipMemcpyHostToDevice));
-    const dim3 g(persistent_grid<LOGN>(num)), b(1024);
+    // KB_GRID: another persistent grid than the library's min(num, CUs) (e.g. a balanced one: every workgroup the same number of polynomials)
+    const dim3 g(getenv("KB_GRID") ? (unsigned)atoi(getenv("KB_GRID")) : persistent_grid<LOGN>(num)), b(1024);
     auto fwd = [&]() {
         if (kind) k_forward15_lit<LOGN><<<g, b>>>(a, dtw, dp, 1, 0, num);
         else k_forward15<4, true><<<g, b>>>(a, dtw, dp, 1, 0, num);
