@@ -611,8 +611,8 @@ mi355ntt_ctx* raw_derive(int device, unsigned n, unsigned division, bool inverse
     u64 root[kMaxPrimes];
     for (unsigned i = 0; i < division; i++) {
         if (q[i] < 3 || !(q[i] & 1) || bits[i] != bit_length(q[i]) || mu[i] != barrett_mu(q[i], bits[i])) return nullptr;
-        // (a Barrett-inexact modulus no longer sends the whole call to the literal kernels: the derived context routes per prime,
-        // as the reference's own decryption_test.cu:47-48 set through forwardNTT_batch needs it -- 2 of its 3 primes are exact)
+        // (a Barrett-inexact modulus does not send the call to the literal stage kernels: the derived context is a class-0 one --
+        // the reference's own decryption_test.cu:47-48 set through forwardNTT_batch runs single-pass kernels on all three primes)
         // entry n/2 of a table is root^bitrev(n/2) = root^1
         if (hipMemcpy(&root[i], d_tab + (size_t)i * n + n / 2, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
         if (root[i] == 0 || root[i] >= q[i]) return nullptr;
@@ -740,10 +740,10 @@ hipError_t raw_run(RawEntry* e, bool inverse, u64* d_a, unsigned n, const u64* d
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);
     if (e->trusted) return inverse ? run_inverse(c, d_a, num, division, 0, s) : run_forward(c, d_a, num, division, 0, s);
     hipError_t err;
-    // A capturing stream takes no part in the hand-over of the entry's guard words between streams: an event recorded outside the
-    // capture cannot be waited for inside it (nor the other way round), and the graph may be replayed next to anything.  Its checked
-    // calls therefore follow the caller's table with the literal kernels -- always the reference's words; a caller who wants the
-    // throughput kernels inside a graph promises the table with mi355ntt_raw_trust_tables (then nothing is shared).
+    // A capturing stream gets no guard record: the graph may be replayed on any stream, next to direct calls that use the record of
+    // the stream it was captured on.  Its checked calls therefore follow the caller's table with the literal kernels -- always the
+    // reference's words; a caller who wants the throughput kernels inside a graph promises the table with mi355ntt_raw_trust_tables
+    // (then nothing is written at all).
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
         return inverse ? compat_inverse_batch(d_a, n, d_tab, num, division, m, s) : compat_forward_batch(d_a, n, d_tab, num, division, m, s);

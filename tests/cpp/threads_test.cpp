@@ -3,12 +3,14 @@
 // call the library at the same time.  Four sections, every result compared word for word with the CPU oracle's, computed up front
 // (the oracle is the checker here, as everywhere under tests/):
 //   1. n = 2^15, four 60-bit primes: the persistent single-pass kernels (192 polynomials per call) and the small-batch path (8)
-//   2. the reference's own decryption_test.cu moduli, n = 4096: a MIXED context -- prime 1 is Barrett-inexact and runs the literal
-//      kernels through the context's single gather buffer, which the streams hand over by an event (capi.cpp, run_mixed)
+//   2. the reference's own decryption_test.cu moduli, n = 4096: a class-0 context -- prime 1 is Barrett-inexact: its polynomials take the
+//      reference's own butterflies, the others the lazy ones, in one launch (kernels_lit.cuh; until round 5 a gather buffer that the
+//      streams handed over by an event)
 //   3. n = 2^16, forward over 96 polynomials: the cooperating-workgroup launch whose flag buffer belongs to one stream at a time
 //      (pair_acquire): the other threads' calls must fall back to the single-workgroup kernel, with the same words
 //   4. the reference-signature raw API on 40 distinct tables: more than the 32 cached contexts, so entries are evicted and
-//      re-derived while other threads use the cache (the mutex-guarded LRU of capi.cpp)
+//      re-derived while other threads use the cache (the mutex-guarded LRU of capi.cpp); every thread calls on a stream of its own and
+//      destroys it when it is done, while the others still call with the same tables (the entries keep a guard record per stream)
 // tests/test_threads.py builds and runs it.   usage: threads_test [threads = 8] [iterations = 4]
 #include <hip/hip_runtime.h>
 
@@ -212,7 +214,7 @@ int main(int argc, char** argv)
     const std::vector<u64> q60 = {1152921504606584833ULL, 1152921504598720513ULL, 1152921504597016577ULL, 1152921504595968001ULL};
     const std::vector<u64> psi60 = {4443670208963ULL, 100545759574150ULL, 31693996050849ULL, 88651361085495ULL};
     context_section("n = 32768, 4 x 60 bits: persistent + small-batch kernels", 32768, q60, psi60, 192, 8, 0);
-    // decryption_test.cu:47-48 (primes 0 and 2 exact, prime 1 not): per-prime routing = 2; 900 polynomials = several chunks of the gather buffer
+    // decryption_test.cu:47-48 (primes 0 and 2 exact, prime 1 not): per-prime routing = 2; 900 polynomials = several polynomials of each kind per workgroup
     context_section("n = 4096, decryption_test.cu moduli: mixed context", 4096, {68719403009ULL, 68719230977ULL, 137438822401ULL},
                     {24250113ULL, 29008497ULL, 8625844ULL}, 900, 6, 2);
     const std::vector<u64> q16 = {q60[0], q60[1]};

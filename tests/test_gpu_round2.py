@@ -132,8 +132,8 @@ def test_raw_api_falls_back_to_literal_kernels(native, oracle, gpu):
     d_oa = dev(native, oa)
     native.forwardNTT_batch(d_oa, kn, d_one, 5, 1, native.Moduli(kq[1:2]))
     assert np.array_equal(host(native, d_oa), oracle.forward_batch(oa, one, threads=THREADS))
-    # ... with the reference's words for every prime: checked calls, a table rewritten in place under them (the literal share of the
-    # mixed context must stand back as well: inverted guard pair), ragged batches over several chunks of the gather buffer, trusted calls
+    # ... with the reference's words for every prime: checked calls, a table rewritten in place under them (both passes of the class-0
+    # kernel must stand back), ragged batches, trusted calls
     for knum in (3, 7, 902):
         ka = oracle.synth_batch(kn, knum, kq, 4100 + knum)
         d_ka = dev(native, ka)

@@ -119,9 +119,9 @@ def test_rccl_is_initialised_and_used_once_world_size_1(native, gpu):
 
 def test_per_prime_literal_routing_on_the_kat1_moduli(native, oracle, gpu):
     """decryption_test.cu's own primes: 0 and 2 are Barrett-exact, prime 1 (68719230977) is not.  The context routes per prime
-    (mi355ntt_ctx_uses_literal_kernels == 2): polynomials of prime 1 through the literal kernels, the others through the throughput
-    kernels -- and every word is the oracle's (the reference's, including its non-canonical outputs on prime 1), for batches that
-    span several gather chunks, ragged tails, sub-ranges of the primes, two streams at once, and the fused-product entry points."""
+    (mi355ntt_ctx_uses_literal_kernels == 2): polynomials of prime 1 through the reference's own butterflies, the others through the lazy
+    ones (since round 6 in one single-pass launch, kernel class 0) -- and every word is the oracle's (the reference's, including its
+    non-canonical outputs on prime 1), for large batches, ragged tails, sub-ranges of the primes, two streams at once, and the fused-product entry points."""
     import torch
     from test_barrett_exactness import KAT_Q, KAT_PSI
     n = 4096
@@ -144,7 +144,7 @@ def test_per_prime_literal_routing_on_the_kat1_moduli(native, oracle, gpu):
         assert np.array_equal(native.to_host(d).reshape(num, n), want_f), ("forward", num)
         ctx.inverse_batch(d, num)
         assert np.array_equal(native.to_host(d).reshape(num, n), oracle.inverse_batch(want_f.copy(), prm).reshape(num, n)), ("inverse", num)
-    # two streams at once on the same context: the gather buffer changes hands in stream order
+    # two streams at once on the same context (nothing is shared between them)
     num = 900
     a = oracle.synth_batch(n, num, KAT_Q, 55).reshape(num, n)
     b = oracle.synth_batch(n, num, KAT_Q, 56).reshape(num, n)
@@ -164,7 +164,7 @@ def test_per_prime_literal_routing_on_the_kat1_moduli(native, oracle, gpu):
     ctx.forward_batch(da, num, stream=s1); ctx.forward_batch(db, num, stream=s2)
     torch.cuda.synchronize()
     assert np.array_equal(native.to_host(da).reshape(num, n), want_a) and np.array_equal(native.to_host(db).reshape(num, n), want_b)
-    # captured into a hipGraph (strided copies become memcpy nodes; the event hand-over is left out inside a capture) and replayed
+    # captured into a hipGraph and replayed
     num = 300
     a = oracle.synth_batch(n, num, KAT_Q, 91).reshape(num, n)
     want = oracle.inverse_batch(oracle.forward_batch(a.copy(), prm), prm).reshape(num, n)

@@ -1,6 +1,6 @@
 """The header's thread-safety contract (include/mi355ntt.h:18-19) from compiled C++: eight std::threads on shared contexts
-(tests/cpp/threads_test.cpp) -- persistent and small-batch kernels at n = 2^15, the mixed context of the reference's own
-decryption_test.cu moduli (gather-buffer hand-over), n = 2^16 pair launches (pair_acquire) and the raw API's LRU under eviction;
+(tests/cpp/threads_test.cpp) -- persistent and small-batch kernels at n = 2^15, the class-0 context of the reference's own
+decryption_test.cu moduli (one launch, two passes per workgroup), n = 2^16 pair launches (pair_acquire) and the raw API's LRU under eviction;
 every result against the CPU oracle (linked into the test program: test infrastructure)."""
 import os
 import subprocess
