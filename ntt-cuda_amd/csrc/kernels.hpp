@@ -127,8 +127,8 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
 hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
                               bool shared_b = false, unsigned group = 0);
 // The fused product of n = 2^15 with a per-prime element-wise epilogue in its store path (kernels_epi.cuh; the batched BFV drivers):
-// kind 1: a <- ((a bhat + other, `>`) k1) k2 for the primes whose record is `on` (decryption, bfv_decryption.cuh:98-122), kind 2:
-// a <- a bhat + other (`>`) (encryption, bfv_encryption.cuh:268-279).  other: a buffer of the shape of d_a; d_consts: `division` records
+// kind 1: a <- (a bhat + other, `>`) k1 mod q (k2 = floor(k1 2^64 / q), the Shoup companion) for the primes whose record is `on` (decryption, bfv_decryption.cuh:98-122; the only kind
+// built -- the encryption's `+ e` was measured slower fused than in k_encrypt_tail: profiles/r06_bfv_batch.txt).  other: a buffer of the shape of d_a; d_consts: `division` records
 // {u64 k1, k2; unsigned on, pad} on the device.  _ok: the call would run without a head / tail cut -- one launch of the persistent kernel or the three
 // small-batch launches, both of which carry the epilogue (else the callers run the product and the element-wise kernel one after the other).
 bool fast_polymul_epi_ok(const FastTables& t, unsigned num, unsigned division);
