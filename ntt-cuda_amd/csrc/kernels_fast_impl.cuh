@@ -759,6 +759,37 @@ inline bool use_latency_path(unsigned num, bool fused)
     return LOGN == 15 && num > 256u && num <= (fused ? 384u : 352u);
 }
 
+// class 0 (kernels_lit.cuh): which of the two kernel shapes a call runs.  The literal butterflies carry 2.6 - 3.2 x the instructions of
+// the lazy ones, so this class is bound by VALU issue and the second pass over memory of the small-batch kernels (a polynomial over
+// n/512 waves, two launches per transform) costs next to nothing -- while their fine-grained workgroups balance any batch size over
+// the chip, where the single-pass kernels (one workgroup per polynomial) take whole rounds of the persistent grid: one polynomial at
+// n = 2^15 154 -> 25 us per forward + inverse, 320 polynomials 320 -> 213 us, 1024 polynomials 641 = 639 us.  Measured switching
+// points (tools/probe/lit_small_ab.py, profiles/r06_literal_class.txt): n <= 2^14 the small-batch kernels up to the batch sizes below;
+// n = 2^15 whenever 25 us + 0.65 us per polynomial beats the whole rounds of 157 us, up to 1024 polynomials (from 1280 polynomials on
+// the batch leaves the memory-side cache and the single pass wins by 3 - 10 %).
+template <int LOGN>
+constexpr unsigned lit_lat_threshold(bool fused)
+{
+    if (LOGN == 14) return fused ? 1024u : 4096u;
+    if (LOGN == 13) return fused ? 704u : 4096u;
+    return 16384u;                                         // n = 2^11, 2^12
+}
+template <int LOGN>
+inline bool lit_use_latency_path(unsigned num, bool fused, unsigned grid)
+{
+    static const long forced = [] {
+        const char* e = std::getenv("MI355NTT_LATENCY_PATH_MAX");
+        return e ? (long)std::strtoul(e, nullptr, 10) : -1L;
+    }();
+    if (forced >= 0) return num <= (unsigned long)forced;
+    if (LOGN == 15) {
+        if (num > 1024u) return false;
+        const unsigned rounds = (num + grid - 1u) / grid;
+        return 25000u + (fused ? 660u : 650u) * num < rounds * 156000u;      // (ns per transform pair / product)
+    }
+    return num <= lit_lat_threshold<LOGN>(fused);
+}
+
 // the context's kernel class (FastTables::hl: bits 0-3 headroom class, bit 4 every prime near 2^k) as compile-time arguments.
 // Classes: 6 (<= 58-bit moduli: no intermediate reduction), 5 (59-bit near-2^k, round 4: one partial reduction every 7 forward / 3 inverse stages
 // instead of every 3 / 2), 4 (59/60-bit: one every 2-3 stages), 3 (61-bit near-2^k, round 4: 8 q < 2^64, so the
@@ -859,7 +890,12 @@ hipError_t launch_fwd(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
 {
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
     using L = LatGeo<LOGN>;
-    if ((hl & 15) == HL_LIT) {      // the reference's own arithmetic (kernels_lit.cuh): single pass at every batch size
+    if ((hl & 15) == HL_LIT) {      // the reference's own arithmetic (kernels_lit.cuh)
+        if (lit_use_latency_path<LOGN>(num, false, lit_grid<LOGN>(num, division))) {
+            k_lat_fwd_a_lit<LOGN><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, tw, pr, division, base);
+            k_lat_fwd_b_lit<LOGN><<<dim3(num << L::CH), dim3(64), 0, s>>>(d_a, tw, pr, division, base);
+            return hipGetLastError();
+        }
         const dim3 gl(lit_grid<LOGN>(num, division));
         if constexpr (LOGN == 15) k_forward15_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_forward_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -890,6 +926,11 @@ hipError_t launch_inv(int hl, u64* d_a, const TwPair* tw, const PrimeDev* pr, un
     dim3 g(persistent_grid<LOGN>(num)), b(Geo<LOGN>::T);
     using L = LatGeo<LOGN>;
     if ((hl & 15) == HL_LIT) {
+        if (lit_use_latency_path<LOGN>(num, false, lit_grid<LOGN>(num, division))) {
+            k_lat_inv_b_lit<LOGN><<<dim3(num << L::CH), dim3(64), 0, s>>>(d_a, tw, pr, division, base);
+            k_lat_inv_a_lit<LOGN><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, tw, pr, division, base);
+            return hipGetLastError();
+        }
         const dim3 gl(lit_grid<LOGN>(num, division));
         if constexpr (LOGN == 15) k_inverse15_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
         else k_inverse_lit<LOGN><<<gl, b, 0, s>>>(d_a, tw, pr, division, base, num);
@@ -919,6 +960,12 @@ hipError_t launch_mul(int hl, u64* d_a, const u64* d_b, const TwPair* twf, const
 {
     using L = LatGeo<LOGN>;
     if ((hl & 15) == HL_LIT) {
+        if (lit_use_latency_path<LOGN>(num, true, lit_grid<LOGN>(num, plain_division(division)))) {
+            k_lat_fwd_a_lit<LOGN><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, twf, pr, plain_division(division), 0u);
+            k_lat_mul_b_lit<LOGN><<<dim3(num << L::CH), dim3(64), 0, s>>>(d_a, d_b, twf, twi, pr, division);
+            k_lat_inv_a_lit<LOGN><<<dim3(num << L::GB), dim3(L::WA), 0, s>>>(d_a, twi, pr, plain_division(division), 0u);
+            return hipGetLastError();
+        }
         if constexpr (LOGN == 15)
             k_polymul15_lit<LOGN><<<dim3(lit_grid<LOGN>(num, plain_division(division))), dim3(Geo<LOGN>::T), 0, s>>>(d_a, d_b, twf, twi, pr, division, num);
         else

@@ -44,21 +44,25 @@ __host__ __device__ constexpr unsigned lat_tw_index(unsigned p)
 template <int LOGN, int HL, bool NEAR, bool TWS, int S>
 __device__ __forceinline__ void lat_ct(u64& a, u64& b, const TwPair w, const PrimeDev& p)
 {
-    constexpr bool EX = Lazy<HL>::EXACT;
-    constexpr bool red = (fwd_reduce_mask<LOGN, HL>() >> S) & 1u;
-    const u64 cq = (u64)Lazy<HL>::TQ * p.q;
-    u64 U = a;
-    if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
-    if constexpr (!EX) {
-        u64 D = (U << 1) + cq;
-        asm("" : "+v"(D));
-        const u64 A = mul_shoup4m_acc<TWS>(b, w.w, w.wp, p.nq, U);
-        a = A;
-        b = D - A;
+    if constexpr (HL == HL_LIT) {
+        lit_ct_bfly(a, b, w.w, p);                        // the reference's own butterfly (kernel class 0, kernels_lit.cuh)
     } else {
-        const u64 Tm = mul_shoup2(b, w.w, w.wp, p.nq);
-        a = U + Tm;
-        b = U + cq - Tm;
+        constexpr bool EX = Lazy<HL>::EXACT;
+        constexpr bool red = (fwd_reduce_mask<LOGN, HL>() >> S) & 1u;
+        const u64 cq = (u64)Lazy<HL>::TQ * p.q;
+        u64 U = a;
+        if constexpr (red) U = reduce_2q_sel<NEAR>(U, p);
+        if constexpr (!EX) {
+            u64 D = (U << 1) + cq;
+            asm("" : "+v"(D));
+            const u64 A = mul_shoup4m_acc<TWS>(b, w.w, w.wp, p.nq, U);
+            a = A;
+            b = D - A;
+        } else {
+            const u64 Tm = mul_shoup2(b, w.w, w.wp, p.nq);
+            a = U + Tm;
+            b = U + cq - Tm;
+        }
     }
 }
 
@@ -66,22 +70,26 @@ __device__ __forceinline__ void lat_ct(u64& a, u64& b, const TwPair w, const Pri
 template <int LOGN, int HL, bool NEAR, bool TWS, int BETA, bool IN2Q = false>
 __device__ __forceinline__ void lat_gs(u64& a, u64& b, const TwPair w, const PrimeDev& p)
 {
-    static_assert(!IN2Q || !Lazy<HL>::EXACT, "lazy inputs: classes with 4q of headroom only (gs_round, ntt_core.cuh)");
-    constexpr InvPolicy<LOGN, HL> POL{};
-    constexpr bool EX = Lazy<HL>::EXACT;
-    constexpr bool last = (BETA == LOGN - 1);
-    constexpr bool red = ((POL.mask >> BETA) & 1u) || (last && !(NEAR && !EX) && (2 * POL.cmul[BETA] > Lazy<HL>::TQ));
-    const u64 cq = (u64)((IN2Q && BETA == 0) ? 2 : POL.cmul[BETA]) * p.q;
-    const u64 X = a, Y = b;
-    u64 S = X + Y;
-    const u64 D = X + cq - Y;
-    if constexpr (red) {
-        if constexpr (EX && !NEAR) S = csub(S, 2 * p.q);
-        else S = reduce_2q_sel<NEAR>(S, p);
+    if constexpr (HL == HL_LIT) {
+        lit_gs_bfly(a, b, w.w, p, (p.q + 1) >> 1);        // the reference's own butterfly, halving included (kernel class 0)
+    } else {
+        static_assert(!IN2Q || !Lazy<HL>::EXACT, "lazy inputs: classes with 4q of headroom only (gs_round, ntt_core.cuh)");
+        constexpr InvPolicy<LOGN, HL> POL{};
+        constexpr bool EX = Lazy<HL>::EXACT;
+        constexpr bool last = (BETA == LOGN - 1);
+        constexpr bool red = ((POL.mask >> BETA) & 1u) || (last && !(NEAR && !EX) && (2 * POL.cmul[BETA] > Lazy<HL>::TQ));
+        const u64 cq = (u64)((IN2Q && BETA == 0) ? 2 : POL.cmul[BETA]) * p.q;
+        const u64 X = a, Y = b;
+        u64 S = X + Y;
+        const u64 D = X + cq - Y;
+        if constexpr (red) {
+            if constexpr (EX && !NEAR) S = csub(S, 2 * p.q);
+            else S = reduce_2q_sel<NEAR>(S, p);
+        }
+        a = S;
+        if constexpr (!EX) b = mul_shoup4m<TWS>(D, w.w, w.wp, p.nq);
+        else b = mul_shoup2(D, w.w, w.wp, p.nq);
     }
-    a = S;
-    if constexpr (!EX) b = mul_shoup4m<TWS>(D, w.w, w.wp, p.nq);
-    else b = mul_shoup2(D, w.w, w.wp, p.nq);
 }
 
 // x * w for the one value per thread that was summed in every stage of the last inverse round (w = n^-1)

@@ -4,7 +4,8 @@
 // class HL_LIT"; capi.cpp).  Until round 5 their polynomials ran the stage-per-launch kernels of kernels_compat.hip (2 passes over
 // memory at n = 2^15, 0.10 of the HBM roofline, plus a gather buffer for contexts that mix both kinds of primes).  These kernels run
 // the register-resident rounds of the lazy classes with the literal butterflies: ONE read and ONE write of HBM per transform, in
-// place, one launch for the whole call.
+// place, one launch for the whole call.  (Small batches: the kernel shape of kernels_lat.cuh with the same butterflies, at the end
+// of this file; which shape a call takes: lit_use_latency_path, kernels_fast_impl.cuh.)
 //
 // A context of this class may hold Barrett-EXACT primes next to the inexact ones -- the reference's own decryption_test.cu:47-48 set:
 // two exact, one not.  For those the reference's words ARE the exact transform's, so their polynomials take the lazy butterflies of
@@ -363,6 +364,179 @@ k_polymul_lit(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* _
     const u64* bp = bhat + (size_t)sb.index(y, idx, division) * G::N;
     if (primes[idx].lit) lit_polymul_one<LOGN, HL_LIT>(poly, bp, twf, twi, primes, idx, lds, wave_s);
     else lit_polymul_one<LOGN, HL_LIT_EXACT>(poly, bp, twf, twi, primes, idx, lds, wave_s);
+}
+
+// ================================================================================================
+// small batches (the shapes of kernels_lat.cuh: a polynomial over n/512 waves of eight coefficients per thread, two launches per
+// transform, three per product).  One workgroup works on one polynomial, so the butterfly kind is picked once at the top of the
+// kernel (nothing is live across the branch): the reference's own butterflies for a Barrett-inexact prime, the lazy class-2 ones
+// for the exact primes of the same context.  Literal values travel between the launches as the reference's memory holds them
+// between its stage launches; nothing is canonicalised and the inverse halves in every stage (no n^-1 table entries).
+// ================================================================================================
+template <int LOGN, int HB>
+__device__ __forceinline__ void lat_lit_fwd_a(u64* __restrict__ poly, const TwPair* __restrict__ twp, const PrimeDev& p, u64* lds, unsigned g,
+                                              unsigned k, unsigned lane)
+{
+    using L = LatGeo<LOGN>;
+    const BufRsrc twr = make_rsrc(twp, L::N * 16u), prs = make_rsrc(poly, L::N * 8u);
+    const unsigned voff = ((g << 6) | lane) * 8u;
+    u64 v[8];
+    static_for<8>([&](auto rc) { constexpr unsigned r = decltype(rc)::value; v[r] = buf_load_u64(prs, voff, ((r << (LOGN - 3)) | (k << (6 + L::GB))) * 8u); });
+    lat_fwd_round<LOGN, HB, false, true, LOGN - 1, L::NST1>(v, twp, twr, p, 0u);
+    if constexpr (L::NST2 > 0) {
+        lat_swap_kr(v, lds, k, lane);
+        lat_fwd_round<LOGN, HB, false, true, LOGN - 4, L::NST2>(v, twp, twr, p, k);
+        static_for<8>([&](auto rc) { constexpr unsigned r = decltype(rc)::value; buf_store_u64(prs, voff, ((k << (LOGN - 3)) | (r << (LOGN - 6))) * 8u, v[r]); });
+    } else {
+        static_for<8>([&](auto rc) { constexpr unsigned r = decltype(rc)::value; buf_store_u64(prs, voff, ((r << (LOGN - 3)) | (k << (6 + L::GB))) * 8u, v[r]); });
+    }
+}
+
+template <int LOGN, int HB>
+__device__ __forceinline__ void lat_lit_inv_a(u64* __restrict__ poly, const TwPair* __restrict__ twp, const PrimeDev& p, const TwPair* __restrict__ twn,
+                                              u64* lds, unsigned g, unsigned k, unsigned lane)
+{
+    using L = LatGeo<LOGN>;
+    constexpr bool SCALE = (HB != HL_LIT);               // (the literal butterflies halve in every stage)
+    const BufRsrc twr = make_rsrc(twp, L::N * 16u), prs = make_rsrc(poly, L::N * 8u);
+    const unsigned voff = ((g << 6) | lane) * 8u;
+    u64 v[8];
+    if constexpr (L::NST2 > 0) {
+        static_for<8>([&](auto rc) { constexpr unsigned r = decltype(rc)::value; v[r] = buf_load_u64(prs, voff, ((k << (LOGN - 3)) | (r << (LOGN - 6))) * 8u); });
+        lat_inv_round<LOGN, HB, false, true, LOGN - 6, L::NST2>(v, twp, twr, p, k);
+        lat_swap_kr(v, lds, k, lane);
+    } else {
+        static_for<8>([&](auto rc) { constexpr unsigned r = decltype(rc)::value; v[r] = buf_load_u64(prs, voff, ((r << (LOGN - 3)) | (k << (6 + L::GB))) * 8u); });
+    }
+    lat_inv_round<LOGN, HB, false, true, LOGN - 3, L::NST1, SCALE>(v, twp, twr, p, 0u, twn);
+    static_for<8>([&](auto rc) {
+        constexpr unsigned r = decltype(rc)::value;
+        buf_store_u64(prs, voff, ((r << (LOGN - 3)) | (k << (6 + L::GB))) * 8u, canon_after_inverse<HB, false>(v[r], p));
+    });
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(LatGeo<LOGN>::WA, 1)
+k_lat_fwd_a_lit(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division, unsigned prime_base)
+{
+    if (guard_says_skip(primes, prime_base)) return;
+    using L = LatGeo<LOGN>;
+    __shared__ u64 lds[L::NST2 ? 4096 : 1];
+    const unsigned y = blockIdx.x >> L::GB, g = blockIdx.x & ((1u << L::GB) - 1u);
+    const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));
+    const PrimeDev p = primes[idx];
+    u64* poly = a + (size_t)y * L::N;
+    const TwPair* twp = tw + (size_t)idx * L::N;
+    if (primes[idx].lit) lat_lit_fwd_a<LOGN, HL_LIT>(poly, twp, p, lds, g, k, lane);
+    else lat_lit_fwd_a<LOGN, HL_LIT_EXACT>(poly, twp, p, lds, g, k, lane);
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(LatGeo<LOGN>::WA, 1)
+k_lat_inv_a_lit(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division, unsigned prime_base)
+{
+    if (guard_says_skip(primes, prime_base)) return;
+    using L = LatGeo<LOGN>;
+    __shared__ u64 lds[L::NST2 ? 4096 : 1];
+    const unsigned y = blockIdx.x >> L::GB, g = blockIdx.x & ((1u << L::GB) - 1u);
+    const unsigned k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));
+    const PrimeDev p = primes[idx];
+    u64* poly = a + (size_t)y * L::N;
+    const TwPair* twp = tw + (size_t)idx * L::N;
+    if (primes[idx].lit) lat_lit_inv_a<LOGN, HL_LIT>(poly, twp, p, primes[idx].twn, lds, g, k, lane);
+    else lat_lit_inv_a<LOGN, HL_LIT_EXACT>(poly, twp, p, primes[idx].twn, lds, g, k, lane);
+}
+
+// the "b" kernels: one wave on 512 consecutive coefficients (index bits 8 .. 0)
+template <int LOGN, int HB>
+__device__ __forceinline__ void lat_lit_fwd_b(const BufRsrc prs, const TwPair* __restrict__ twp, const PrimeDev& p, u64* slice, unsigned c, unsigned lane)
+{
+    const BufRsrc twr = make_rsrc(twp, (1u << LOGN) * 16u);
+    u64 v[8];
+    lat_load_l6(v, prs, c, lane);
+    lat_fwd_b_rounds<LOGN, HB, false>(v, twp, twr, p, slice, c, lane);
+    static_for<8>([&](auto rc) { constexpr int r = decltype(rc)::value; v[r] = canon_after_forward<HB, false>(v[r], p); });
+    lat_store_l0(v, prs, c, lane);
+}
+template <int LOGN, int HB>
+__device__ __forceinline__ void lat_lit_inv_b(const BufRsrc prs, const TwPair* __restrict__ twp, const PrimeDev& p, u64* slice, unsigned c, unsigned lane)
+{
+    const BufRsrc twr = make_rsrc(twp, (1u << LOGN) * 16u);
+    u64 v[8];
+    lat_load_l0(v, prs, c, lane);
+    lat_inv_b_rounds<LOGN, HB, false>(v, twp, twr, p, slice, c, lane);
+    lat_store_l6(v, prs, c, lane);
+}
+template <int LOGN, int HB>
+__device__ __forceinline__ void lat_lit_mul_b(const BufRsrc prs, const BufRsrc brs, const TwPair* __restrict__ tf, const TwPair* __restrict__ ti,
+                                              const PrimeDev& p, u64* slice, unsigned c, unsigned lane)
+{
+    const BufRsrc tfr = make_rsrc(tf, (1u << LOGN) * 16u), tir = make_rsrc(ti, (1u << LOGN) * 16u);
+    u64 v[8], bb[8];
+    lat_load_l6(v, prs, c, lane);
+    lat_load_l0(bb, brs, c, lane);
+    lat_fwd_b_rounds<LOGN, HB, false>(v, tf, tfr, p, slice, c, lane);
+    static_for<8>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        v[r] = FusedMul<HB, false>::mul(v[r], bb[r], p);
+    });
+    lat_inv_b_rounds<LOGN, HB, false, FusedMul<HB, false>::LAZY>(v, ti, tir, p, slice, c, lane);
+    lat_store_l6(v, prs, c, lane);
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(64, 1)
+k_lat_fwd_b_lit(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division, unsigned prime_base)
+{
+    if (guard_says_skip(primes, prime_base)) return;
+    __shared__ u64 slice[LAT_SLICE_WORDS];
+    const unsigned y = blockIdx.x >> (LOGN - 9), c = blockIdx.x & ((1u << (LOGN - 9)) - 1u), lane = threadIdx.x;
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * (1u << LOGN);
+    const BufRsrc prs = make_rsrc(a + (size_t)y * (1u << LOGN), (1u << LOGN) * 8u);
+    if (primes[idx].lit) lat_lit_fwd_b<LOGN, HL_LIT>(prs, twp, p, slice, c, lane);
+    else lat_lit_fwd_b<LOGN, HL_LIT_EXACT>(prs, twp, p, slice, c, lane);
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(64, 1)
+k_lat_inv_b_lit(u64* __restrict__ a, const TwPair* __restrict__ tw, const PrimeDev* __restrict__ primes, unsigned division, unsigned prime_base)
+{
+    if (guard_says_skip(primes, prime_base)) return;
+    __shared__ u64 slice[LAT_SLICE_WORDS];
+    const unsigned y = blockIdx.x >> (LOGN - 9), c = blockIdx.x & ((1u << (LOGN - 9)) - 1u), lane = threadIdx.x;
+    unsigned idx = __builtin_amdgcn_readfirstlane(prime_base + y % division);
+    asm volatile("" : "+s"(idx));
+    const PrimeDev p = primes[idx];
+    const TwPair* twp = tw + (size_t)idx * (1u << LOGN);
+    const BufRsrc prs = make_rsrc(a + (size_t)y * (1u << LOGN), (1u << LOGN) * 8u);
+    if (primes[idx].lit) lat_lit_inv_b<LOGN, HL_LIT>(prs, twp, p, slice, c, lane);
+    else lat_lit_inv_b<LOGN, HL_LIT_EXACT>(prs, twp, p, slice, c, lane);
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(64, 1)
+k_lat_mul_b_lit(u64* __restrict__ a, const u64* __restrict__ bhat, const TwPair* __restrict__ twf, const TwPair* __restrict__ twi,
+                const PrimeDev* __restrict__ primes, unsigned division)
+{
+    const SharedB sb(division);
+    __shared__ u64 slice[LAT_SLICE_WORDS];
+    const unsigned y = blockIdx.x >> (LOGN - 9), c = blockIdx.x & ((1u << (LOGN - 9)) - 1u), lane = threadIdx.x;
+    unsigned idx = __builtin_amdgcn_readfirstlane(y % division);
+    asm volatile("" : "+s"(idx));
+    const PrimeDev p = primes[idx];
+    const TwPair* tf = twf + (size_t)idx * (1u << LOGN);
+    const TwPair* ti = twi + (size_t)idx * (1u << LOGN);
+    const BufRsrc prs = make_rsrc(a + (size_t)y * (1u << LOGN), (1u << LOGN) * 8u);
+    const BufRsrc brs = make_rsrc(bhat + (size_t)sb.index(y, idx, division) * (1u << LOGN), (1u << LOGN) * 8u);
+    if (primes[idx].lit) lat_lit_mul_b<LOGN, HL_LIT>(prs, brs, tf, ti, p, slice, c, lane);
+    else lat_lit_mul_b<LOGN, HL_LIT_EXACT>(prs, brs, tf, ti, p, slice, c, lane);
 }
 
 }  // namespace mi355ntt

@@ -50,7 +50,9 @@ def test_literal_class_matches_oracle_word_for_word(native, oracle, gpu, n, kind
     per_cu = {2048: 16, 4096: 8, 8192: 4, 16384: 2, 32768: 1}[n]
     big = 256 * per_cu * 2 + 5 * len(qs) + 1 if n <= 4096 else 256 * per_cu + 67      # beyond one polynomial per resident workgroup
     seen_noncanonical = False
-    for num in (1, len(qs) + 2, big):
+    # (n = 2^15: two whole rounds of the persistent grid -- 255 workgroups when the prime count shares a factor with 256 -- take the
+    # single-pass shape by the default rule, the other sizes the small-batch shape)
+    for num in (1, len(qs) + 2, big) + (((510 if kind == "mixed" else 512),) if n == 32768 else ()):
         a = _adversarial(oracle.synth_batch(n, num, qs, 300 + num).reshape(num, n), qs, rng)
         want_f = oracle.forward_batch(a.copy(), prm, threads=8).reshape(num, n)
         d = native.to_device(a)
@@ -209,3 +211,20 @@ def test_checked_raw_calls_share_nothing_between_streams(native, oracle, gpu):
         s.synchronize()
         assert np.array_equal(native.to_host(d).reshape(num, n), want2), ("rewritten table", i)
     native.raw_cache_clear()
+
+
+@pytest.mark.parametrize("forced", ["0", "1000000"])
+def test_both_kernel_shapes_of_class_0_at_every_batch_size(forced):
+    """Class 0 has two kernel shapes -- single-pass (one workgroup per polynomial) and small-batch (a polynomial over n/512 waves, two
+    launches per transform) -- and picks by batch size.  MI355NTT_LATENCY_PATH_MAX (read once per process) forces one of them for every
+    size: the word-for-word tests above, the moduli sweep and the KAT-1 routing test pass either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI355NTT_LATENCY_PATH_MAX=forced)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_round6.py"), os.path.join(root, "tests", "test_gpu_round4.py"),
+                        "-k", "word_for_word or arbitrary_words or per_prime_literal_routing"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
