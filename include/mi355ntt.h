@@ -86,8 +86,9 @@ int mi355ntt_get_params(unsigned n, mi355ntt_u64* q, mi355ntt_u64* psi, mi355ntt
  * prime of the context (for the exact ones the literal words ARE the exact transform's), at every batch size and under stream
  * capture like any other call (round 6; until round 5 these polynomials went through stage-per-launch kernels and a gather
  * buffer).  MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES passed to mi355ntt_ctx_create_ex selects the exact (lazy-arithmetic) kernels
- * regardless.  n = 65536 contexts with an inexact prime run the literal stage-per-launch kernels (the reference's dispatch ends at
- * n = 32768, ntt_60bit.cuh:316-347).
+ * regardless.  n = 65536 (beyond the reference's dispatch, ntt_60bit.cuh:316-347) runs the reference's coupling stage in memory
+ * around two half-size class-0 transforms (up to 8 primes; more, and inexact primes narrower than 34 or wider than 61 bits, run the
+ * literal stage-per-launch kernels).  Small batches run kernels of their own that spread a polynomial over many waves.
  * ---------------------------------------------------------------------------------------------- */
 #define MI355NTT_CTX_EXACT_ON_INEXACT_PRIMES 1u
 int mi355ntt_ctx_create(mi355ntt_ctx** out, unsigned n, unsigned num_primes,

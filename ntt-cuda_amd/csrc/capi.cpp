@@ -53,8 +53,8 @@ struct mi355ntt_ctx {
     //                     class HL_LIT of the single-pass kernels (round 6: one read and one write per transform, every prime of the
     //                     context -- for the exact ones the literal words ARE the exact transform's; no gather buffer, no per-prime
     //                     routing, nothing special under stream capture);
-    //   literal_stages -- ... at n = 2^16 (beyond the reference's dispatch and the single-pass kernels): the stage-per-launch kernels
-    //                     of kernels_compat.hip;
+    //   literal_stages -- ... with an inexact prime narrower than 34 or wider than 61 bits, or at n = 2^16 with more than 8 primes: the
+    //                     stage-per-launch kernels of kernels_compat.hip (n = 2^16 otherwise: `split16` below with class-0 tables);
     //   mixed          -- some, not all, primes inexact (reported by mi355ntt_ctx_uses_literal_kernels as 2; routing as `literal`).
     bool literal = false, literal_stages = false, mixed = false;
     unsigned inexact_mask = 0;
@@ -235,9 +235,11 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
     }
     if (c->inexact_mask) {
         c->literal = true;
-        // the single-pass literal kernels serve n <= 2^15 and inexact moduli of 34 ... 61 bits (ntt_core.cuh, lit_barrett_mul: both
-        // 128-bit shifts of singleBarrett as funnel shifts of 32-bit words); anything else keeps the stage-per-launch kernels
-        c->literal_stages = (n == 65536);
+        // the class-0 kernels serve inexact moduli of 34 ... 61 bits (ntt_core.cuh, lit_barrett_mul: both 128-bit shifts of
+        // singleBarrett as funnel shifts of 32-bit words) -- n = 2^16 as the literal coupling stage in memory around two half-size
+        // class-0 transforms on the derived tables (up to 8 primes, as for the lazy classes); anything else keeps the
+        // stage-per-launch kernels
+        c->literal_stages = (n == 65536 && 2 * num_primes > kMaxPrimes);
         for (unsigned i = 0; i < num_primes; i++)
             if (((c->inexact_mask >> i) & 1u) && (c->prime[i].k < 34 || c->prime[i].k > 61)) c->literal_stages = true;
         c->mixed = !c->literal_stages && c->inexact_mask != (num_primes >= 32 ? ~0u : (1u << num_primes) - 1u);
@@ -264,7 +266,7 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
         g_last_hip_error = (int)e;
         return fail(e == hipErrorOutOfMemory ? MI355NTT_ENOMEM : MI355NTT_EHIP);
     }
-    if (n == 65536 && !c->literal && 2 * num_primes <= kMaxPrimes) {
+    if (n == 65536 && !c->literal_stages && 2 * num_primes <= kMaxPrimes) {
         const unsigned h_n = n / 2;
         std::vector<u64> vp((size_t)2 * num_primes * h_n), vi((size_t)2 * num_primes * h_n);
         PrimeParams vprime[kMaxPrimes];
@@ -287,7 +289,7 @@ int mi355ntt_ctx_create_ex(mi355ntt_ctx** out, unsigned n, unsigned num_primes, 
                         ti[L + p] = hi[(size_t)i * n + 2 * L + h * L + p];
                     }
             }
-        e = fast_tables_create(&c->fast, h_n, 2 * num_primes, vprime, vp.data(), vi.data(), nullptr, nullptr, split_fwd, split_inv);
+        e = fast_tables_create(&c->fast, h_n, 2 * num_primes, vprime, vp.data(), vi.data(), nullptr, nullptr, split_fwd, split_inv, c->literal);
         c->split16 = (e == hipSuccess);
     } else {
         e = fast_tables_create(&c->fast, n, num_primes, c->prime, hp.data(), hi.data(), c->d_psi, c->d_psiinv, nullptr, nullptr,

@@ -424,8 +424,15 @@ hipError_t fast_forward_batch(const FastTables& t, u64* d_a, unsigned num, unsig
 
 // n = 2^16 as two half-size transforms per polynomial with the coupling stage fused into the lower half's loads (t holds the
 // 2 P "virtual primes" of n/2 = 2^15; num, division, prime_base count full-size polynomials / real primes)
-bool fast_forward_split16_ok(const FastTables& t, unsigned num) { return t.log_n == 15 && fast_split_ok_16(num, 0, fast_fwd_pair_ok_16(t.hl)); }
-bool fast_inverse_split16_ok(const FastTables& t, unsigned num, bool product) { return t.log_n == 15 && fast_split_ok_16(num, product ? 2 : 1, false); }
+// (class 0 has no fused forms: its coupling stage is the literal stage kernel in memory)
+bool fast_forward_split16_ok(const FastTables& t, unsigned num)
+{
+    return t.log_n == 15 && (t.hl & 15) != HL_LIT && fast_split_ok_16(num, 0, fast_fwd_pair_ok_16(t.hl));
+}
+bool fast_inverse_split16_ok(const FastTables& t, unsigned num, bool product)
+{
+    return t.log_n == 15 && (t.hl & 15) != HL_LIT && fast_split_ok_16(num, product ? 2 : 1, false);
+}
 hipError_t fast_forward_split16(const FastTables& t, u64* d_a, unsigned num, unsigned division, unsigned prime_base, hipStream_t s)
 {
     // two workgroups per polynomial (k_forward15_pair: 1 x / 1 x traffic) when this stream may own the device's pair flags

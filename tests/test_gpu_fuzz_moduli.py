@@ -172,7 +172,7 @@ def test_modulus_against_oracle(native, oracle, gpu, idx):
         prm = oracle.Params(n, [q], [psi])
         ctx = native.NTTContext(n, [q], [psi])
         # (Barrett-inexact moduli of 34 ... 61 bits run the reference's own arithmetic in the single-pass kernels up to n = 2^15: class 0)
-        single_pass_literal = (not exact) and n <= 32768 and 34 <= q.bit_length() <= 61
+        single_pass_literal = (not exact) and 34 <= q.bit_length() <= 61      # (n = 2^16: two half-size class-0 transforms around the literal coupling stage)
         assert ctx.kernel_class == ((0, False) if single_pass_literal else expected_class([q])), (name, q, n, ctx.kernel_class)
         assert ctx.literal_routing == (0 if exact else 1), (name, q, n)
         small, large = BATCHES[n]

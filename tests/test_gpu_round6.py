@@ -21,12 +21,24 @@ def _adversarial(a, qs, rng):
     return a
 
 
+def _root(q, n):
+    """a primitive 2n-th root of unity mod q (q = 1 mod 2n)"""
+    assert (q - 1) % (2 * n) == 0
+    for g in range(2, 1000):
+        w = pow(g, (q - 1) // (2 * n), q)
+        if pow(w, n, q) == q - 1:
+            return w
+    raise ValueError(q)
+
+
 def _moduli(kind, n):
     if kind == "inexact60":            # one Barrett-inexact 60-bit modulus: every polynomial through the literal butterflies
         q, r = P.INEXACT_PRIMES[60]
         return [q], [r[n]]
     if kind == "mixed":                # inexact 36-bit, exact 60-bit, inexact 61-bit, exact 36-bit: both passes of a workgroup's walk
         sel = [P.INEXACT_PRIMES[36], P.EXACT_NEIGHBOURS[60], P.INEXACT_PRIMES[61], P.EXACT_NEIGHBOURS[36]]
+        if n == 65536:                 # (the exact neighbours are 1 mod 2^16 only: the bench's 60-bit primes stand in)
+            sel = [P.INEXACT_PRIMES[36], (P.Q60[0], {n: _root(P.Q60[0], n)}), P.INEXACT_PRIMES[61], (P.Q60[1], {n: _root(P.Q60[1], n)})]
         return [q for q, _ in sel], [r[n] for _, r in sel]
     if kind == "inexact3":             # three inexact moduli of 34, 50 and 60 bits
         sel = [P.INEXACT_PRIMES[34], P.INEXACT_PRIMES[50], P.INEXACT_PRIMES[60]]
@@ -34,7 +46,7 @@ def _moduli(kind, n):
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384, 32768, 65536])
 @pytest.mark.parametrize("kind", ["inexact60", "mixed", "inexact3"])
 def test_literal_class_matches_oracle_word_for_word(native, oracle, gpu, n, kind):
     """forward, inverse and the fused product of a class-0 context: every word the oracle's, non-canonical ones included, for a few
@@ -47,8 +59,8 @@ def test_literal_class_matches_oracle_word_for_word(native, oracle, gpu, n, kind
     assert ctx.literal_routing == (2 if kind == "mixed" else 1)
     prm = oracle.Params(n, qs, psis)
     rng = np.random.default_rng(n + len(qs))
-    per_cu = {2048: 16, 4096: 8, 8192: 4, 16384: 2, 32768: 1}[n]
-    big = 256 * per_cu * 2 + 5 * len(qs) + 1 if n <= 4096 else 256 * per_cu + 67      # beyond one polynomial per resident workgroup
+    per_cu = {2048: 16, 4096: 8, 8192: 4, 16384: 2, 32768: 1, 65536: 1}[n]
+    big = 256 * per_cu * 2 + 5 * len(qs) + 1 if n <= 4096 else (256 * per_cu + 67 if n <= 32768 else 131)      # beyond one polynomial per resident workgroup
     seen_noncanonical = False
     # (n = 2^15: two whole rounds of the persistent grid -- 255 workgroups when the prime count shares a factor with 256 -- take the
     # single-pass shape by the default rule, the other sizes the small-batch shape)
@@ -68,7 +80,7 @@ def test_literal_class_matches_oracle_word_for_word(native, oracle, gpu, n, kind
         got = native.to_host(d).reshape(num, n)
         bad = np.nonzero((got != want_i).any(axis=1))[0]
         assert bad.size == 0, ("inverse", n, kind, num, bad[:8])
-        if num != big or n <= 8192:
+        if num != big or n <= 8192 or n == 65536:
             b = oracle.synth_batch(n, num, qs, 700 + num).reshape(num, n)
             da = native.to_device(a)
             ctx.polymul_batch(da, native.to_device(b), num)
