@@ -129,8 +129,9 @@ hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, 
 // The fused product of n = 2^15 with a per-prime element-wise epilogue in its store path (kernels_epi.cuh; the batched BFV drivers):
 // kind 1: a <- (a bhat + other, `>`) k1 mod q (k2 = floor(k1 2^64 / q), the Shoup companion) for the primes whose record is `on` (decryption, bfv_decryption.cuh:98-122; the only kind
 // built -- the encryption's `+ e` was measured slower fused than in k_encrypt_tail: profiles/r06_bfv_batch.txt).  other: a buffer of the shape of d_a; d_consts: `division` records
-// {u64 k1, k2; unsigned on, pad} on the device.  _ok: the call would run without a head / tail cut -- one launch of the persistent kernel or the three
-// small-batch launches, both of which carry the epilogue (else the callers run the product and the element-wise kernel one after the other).
+// {u64 k1, k2; unsigned on, pad} on the device.  _ok: ring degree and class take the fused form at all (else, and when fast_polymul_batch_epi
+// returns hipErrorNotSupported -- a class whose persistent kernel does not hold the epilogue --, the callers run the product and the
+// element-wise kernel one after the other).  A batch of k full rounds of the grid plus a short tail is cut as fast_polymul_batch cuts it.
 bool fast_polymul_epi_ok(const FastTables& t, unsigned num, unsigned division);
 hipError_t fast_polymul_batch_epi(const FastTables& t, int kind, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
                                   bool shared_b, unsigned group, const u64* d_other, const void* d_consts);

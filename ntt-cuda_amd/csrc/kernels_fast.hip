@@ -488,8 +488,29 @@ hipError_t fast_pointwise(const FastTables& t, u64* d_c, const u64* d_a, const u
 bool fast_polymul_epi_ok(const FastTables& t, unsigned num, unsigned division)
 {
     static const bool off = std::getenv("MI355NTT_NO_FUSED_EPILOGUE") != nullptr;      // (A/B measurements)
-    if (off || t.log_n != 15 || (t.hl & 15) == HL_LIT || num == 0) return false;
-    return !tail_split_head(t, num, division, true);     // (one persistent launch, or the three small-batch launches)
+    (void)division;
+    return !(off || t.log_n != 15 || (t.hl & 15) == HL_LIT || num == 0);
+}
+
+// Head / tail cut of a fused product (tail_split_head) with the second operands of the tail: one per polynomial -> the same offset;
+// shared by the batch -> the same `division` polynomials; shared per key group -> the group the tail lies in (one group: indexed
+// from its start, no group arithmetic left), or, when the tail starts on a group boundary, the groups from there on.  0: no cut.
+static unsigned polymul_split(const FastTables& t, unsigned num, unsigned division, bool shared_b, unsigned group, const u64* d_bhat,
+                              const u64** b_tail, unsigned* group_tail)
+{
+    unsigned head = tail_split_head(t, num, division, true);
+    *b_tail = d_bhat;
+    *group_tail = group;
+    if (!head) return 0;
+    if (!shared_b) {
+        *b_tail = d_bhat + (size_t)head * t.n;
+    } else if (group) {
+        const unsigned g0 = head / group, g1 = (num - 1) / group;
+        if (g0 == g1) { *b_tail = d_bhat + (size_t)g0 * division * t.n; *group_tail = 0; }
+        else if (head % group == 0) *b_tail = d_bhat + (size_t)g0 * division * t.n;
+        else head = 0;                                       // (a tail across a group boundary that it does not start on: no cut)
+    }
+    return head;
 }
 
 hipError_t fast_polymul_batch_epi(const FastTables& t, int kind, u64* d_a, const u64* d_bhat, unsigned num, unsigned division, hipStream_t s,
@@ -497,6 +518,15 @@ hipError_t fast_polymul_batch_epi(const FastTables& t, int kind, u64* d_a, const
 {
     if (!fast_polymul_epi_ok(t, num, division)) return hipErrorNotSupported;
     if (shared_b && (division > kDivisionMask || group >= (kSharedB >> kSharedGroupShift) || (group && group % division))) return hipErrorInvalidValue;
+    const u64* b_tail;
+    unsigned group_tail;
+    if (const unsigned head = polymul_split(t, num, division, shared_b, group, d_bhat, &b_tail, &group_tail)) {
+        // the head on the persistent kernel (hipErrorNotSupported for a class that does not hold the epilogue: nothing has been launched
+        // then and the caller runs the two steps), the tail on the small-batch kernels, which hold it for every class
+        const hipError_t e = fast_polymul_batch_epi(t, kind, d_a, d_bhat, head, division, s, shared_b, group, d_other, d_consts);
+        return e != hipSuccess ? e : fast_polymul_batch_epi(t, kind, d_a + (size_t)head * t.n, b_tail, num - head, division, s, shared_b, group_tail,
+                                                            d_other + (size_t)head * t.n, d_consts);
+    }
     if (shared_b) division |= kSharedB | (group << kSharedGroupShift);
     return fast_mul_epi_15(kind, t.hl, d_a, d_bhat, reinterpret_cast<const TwPair*>(t.d_fwd), reinterpret_cast<const TwPair*>(t.d_inv),
                            reinterpret_cast<const PrimeDev*>(t.d_primes), num, division, s, d_other, d_consts);
@@ -507,24 +537,11 @@ hipError_t fast_polymul_batch(const FastTables& t, u64* d_a, const u64* d_bhat, 
 {
     const unsigned plain_division = division;
     if (shared_b && (division > kDivisionMask || group >= (kSharedB >> kSharedGroupShift) || (group && group % division))) return hipErrorInvalidValue;
-    if (unsigned head = tail_split_head(t, num, division, true)) {
-        // the tail's second operands: one per polynomial -> the same offset; shared by the batch -> the same `division` polynomials;
-        // shared per key group -> the group the tail lies in (one group: indexed from its start, no group arithmetic left), or, when
-        // the tail starts on a group boundary, the groups from there on
-        const u64* b_tail = d_bhat;
-        unsigned group_tail = group;
-        if (!shared_b) {
-            b_tail = d_bhat + (size_t)head * t.n;
-        } else if (group) {
-            const unsigned g0 = head / group, g1 = (num - 1) / group;
-            if (g0 == g1) { b_tail = d_bhat + (size_t)g0 * division * t.n; group_tail = 0; }
-            else if (head % group == 0) b_tail = d_bhat + (size_t)g0 * division * t.n;
-            else head = 0;                                   // (a tail across a group boundary that it does not start on: no split)
-        }
-        if (head) {
-            const hipError_t e = fast_polymul_batch(t, d_a, d_bhat, head, division, s, shared_b, group);
-            return e != hipSuccess ? e : fast_polymul_batch(t, d_a + (size_t)head * t.n, b_tail, num - head, division, s, shared_b, group_tail);
-        }
+    const u64* b_tail;
+    unsigned group_tail;
+    if (const unsigned head = polymul_split(t, num, division, shared_b, group, d_bhat, &b_tail, &group_tail)) {
+        const hipError_t e = fast_polymul_batch(t, d_a, d_bhat, head, division, s, shared_b, group);
+        return e != hipSuccess ? e : fast_polymul_batch(t, d_a + (size_t)head * t.n, b_tail, num - head, division, s, shared_b, group_tail);
     }
     if (shared_b) division |= kSharedB | (group << kSharedGroupShift);
     const TwPair* twf = reinterpret_cast<const TwPair*>(t.d_fwd);

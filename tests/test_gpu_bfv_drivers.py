@@ -151,11 +151,13 @@ def test_decrypt_with_moduli_wider_than_gamma_matches_oracle(native, oracle, gpu
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,nprimes,count,literal", [(4096, 3, 5, False), (32768, 4, 7, False), (32768, 60, 64, False), (4096, 0, 3, True),
-                                                     (65536, 2, 3, False)])
+                                                     (65536, 2, 3, False), (32768, 60, 52, False), (32768, 60, 110, False)])
 def test_batched_drivers_equal_looped_single_calls(native, oracle, gpu, n, nprimes, count, literal):
     """mi355ntt_bfv_encrypt_batch / _decrypt_batch over `count` ciphertexts (layout [2][count][R][n]) leave, for each
     ciphertext, exactly the words the single drivers leave (those are pinned on the oracle above) -- on the fused
-    product kernels, on the three-step composition (n = 65536) and on the literal kernels (KAT-1 moduli)."""
+    product kernels, on the three-step composition (n = 65536) and on the literal kernels (KAT-1 moduli).  64, 52 and 110 ciphertexts on
+    4 + 1 primes: 320 / 260 / 550 polynomials per product = one or two full rounds of the persistent grid plus a short tail -- the head
+    on the persistent kernel, the tail on the small-batch kernels, both with the decryption's scaling step in their store path."""
     import torch
     from ntt_cuda_amd import bfv
     if literal:
